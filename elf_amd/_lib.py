@@ -1,0 +1,75 @@
+"""ctypes loader for libelfhip.so (the C-ABI of include/elfhip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or fails to load, importing
+this module's `lib()` raises.  Nothing here touches oracle/.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libelfhip.so")
+
+AMERICAN, RUSSIAN, UGOLKI, GO19 = 0, 1, 2, 3
+F32, BF16, BITS = 0, 1, 2
+
+# every symbol include/elfhip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "elfhip_last_error", "elfhip_device_count", "elfhip_abi_version", "elfhip_game_get_info",
+    "elfhip_boards_create", "elfhip_boards_destroy", "elfhip_boards_set_stream", "elfhip_boards_count",
+    "elfhip_boards_game", "elfhip_boards_reset", "elfhip_boards_export", "elfhip_boards_import",
+    "elfhip_boards_legal_mask", "elfhip_boards_step", "elfhip_boards_features", "elfhip_boards_evaluate",
+    "elfhip_boards_playout",
+]
+
+
+class GameInfo(C.Structure):
+    _fields_ = [("num_actions", C.c_int), ("mask_words", C.c_int), ("state_words", C.c_int),
+                ("num_planes", C.c_int), ("board_size", C.c_int), ("max_ply", C.c_int)]
+
+
+class ElfHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ElfHipError(
+            "libelfhip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "there is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i, u64 = C.c_void_p, C.c_int, C.c_uint64
+    L.elfhip_last_error.restype = C.c_char_p
+    L.elfhip_game_get_info.argtypes = [i, C.POINTER(GameInfo)]
+    L.elfhip_boards_create.argtypes = [i, i, i, C.POINTER(vp)]
+    L.elfhip_boards_destroy.argtypes = [vp]
+    L.elfhip_boards_set_stream.argtypes = [vp, vp]
+    L.elfhip_boards_count.argtypes = [vp]
+    L.elfhip_boards_game.argtypes = [vp]
+    L.elfhip_boards_reset.argtypes = [vp]
+    L.elfhip_boards_export.argtypes = [vp, vp]
+    L.elfhip_boards_import.argtypes = [vp, vp]
+    L.elfhip_boards_legal_mask.argtypes = [vp, vp, vp]
+    L.elfhip_boards_step.argtypes = [vp, vp, vp]
+    L.elfhip_boards_features.argtypes = [vp, vp, i]
+    L.elfhip_boards_evaluate.argtypes = [vp, vp]
+    L.elfhip_boards_playout.argtypes = [vp, i, u64, u64, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc < 0:
+        raise ElfHipError("elfhip error %d: %s" % (rc, lib().elfhip_last_error().decode()))
+    return rc
+
+
+def game_info(game):
+    gi = GameInfo()
+    check(lib().elfhip_game_get_info(game, C.byref(gi)))
+    return gi

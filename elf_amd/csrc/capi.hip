@@ -1,0 +1,144 @@
+// extern "C" surface of libelfhip.so (declared in include/elfhip.h).  No exceptions leave this file.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void elfhip_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct elfhip_boards { BoardSlab* slab; };
+
+extern "C" {
+
+const char* elfhip_last_error(void) { return g_err; }
+
+int elfhip_abi_version(void) { return 1; }
+
+int elfhip_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    elfhip_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    return ELFHIP_EHIP;
+  }
+  return n;
+}
+
+int elfhip_game_get_info(int game, elfhip_game_info* out) {
+  if (!out) { elfhip_set_error("game_get_info: null out"); return ELFHIP_EINVAL; }
+  switch (game) {
+    case ELFHIP_AMERICAN: *out = {170, 3, 6, 36, 8, 250}; return ELFHIP_OK;
+    case ELFHIP_GO19: *out = {362, 6, 60, 18, 19, 722}; return ELFHIP_OK;
+    default: elfhip_set_error("game_get_info: unknown or unbuilt game %d", game); return ELFHIP_EINVAL;
+  }
+}
+
+int elfhip_boards_create(int game, int n_boards, int device, elfhip_boards** out) {
+  if (!out) { elfhip_set_error("boards_create: null out"); return ELFHIP_EINVAL; }
+  *out = nullptr;
+  if (n_boards <= 0 || n_boards > (1 << 26)) {
+    elfhip_set_error("boards_create: n_boards=%d out of range [1, 2^26]", n_boards);
+    return ELFHIP_EINVAL;
+  }
+  int ndev = elfhip_device_count();
+  if (ndev < 0) return ndev;
+  if (device < 0 || device >= ndev) {
+    elfhip_set_error("boards_create: device %d not in [0,%d)", device, ndev);
+    return ELFHIP_EINVAL;
+  }
+  HIPCHECK(hipSetDevice(device));
+  BoardSlab* s = nullptr;
+  switch (game) {
+    case ELFHIP_AMERICAN: s = elfhip_make_american(); break;
+    case ELFHIP_GO19: s = elfhip_make_go19(); break;
+    default: break;
+  }
+  if (!s) { elfhip_set_error("boards_create: unknown or unbuilt game %d", game); return ELFHIP_EINVAL; }
+  s->game = game; s->n = n_boards; s->device = device;
+  int rc = s->alloc();
+  if (rc != ELFHIP_OK) { delete s; return rc; }
+  elfhip_boards* h = new (std::nothrow) elfhip_boards{s};
+  if (!h) { delete s; elfhip_set_error("boards_create: host allocation failed"); return ELFHIP_ENOMEM; }
+  *out = h;
+  return ELFHIP_OK;
+}
+
+#define CHECK_H(b)                                                         \
+  if (!(b) || !(b)->slab) { elfhip_set_error("%s: null handle", __func__); return ELFHIP_EINVAL; } \
+  HIPCHECK(hipSetDevice((b)->slab->device));
+
+int elfhip_boards_destroy(elfhip_boards* b) {
+  if (!b) return ELFHIP_OK;
+  if (b->slab) {
+    (void)hipSetDevice(b->slab->device);
+    (void)hipStreamSynchronize(b->slab->stream);
+    delete b->slab;
+  }
+  delete b;
+  return ELFHIP_OK;
+}
+
+int elfhip_boards_set_stream(elfhip_boards* b, void* hip_stream) {
+  CHECK_H(b);
+  b->slab->stream = (hipStream_t)hip_stream;
+  return ELFHIP_OK;
+}
+
+int elfhip_boards_count(const elfhip_boards* b) { return (b && b->slab) ? b->slab->n : ELFHIP_EINVAL; }
+int elfhip_boards_game(const elfhip_boards* b) { return (b && b->slab) ? b->slab->game : ELFHIP_EINVAL; }
+
+int elfhip_boards_reset(elfhip_boards* b) { CHECK_H(b); return b->slab->reset(); }
+
+int elfhip_boards_export(elfhip_boards* b, uint64_t* h_states) {
+  CHECK_H(b);
+  if (!h_states) { elfhip_set_error("boards_export: null buffer"); return ELFHIP_EINVAL; }
+  return b->slab->export_states(h_states);
+}
+
+int elfhip_boards_import(elfhip_boards* b, const uint64_t* h_states) {
+  CHECK_H(b);
+  if (!h_states) { elfhip_set_error("boards_import: null buffer"); return ELFHIP_EINVAL; }
+  return b->slab->import_states(h_states);
+}
+
+int elfhip_boards_legal_mask(elfhip_boards* b, uint64_t* d_mask, uint8_t* d_terminal) {
+  CHECK_H(b);
+  if (!d_mask) { elfhip_set_error("boards_legal_mask: null d_mask"); return ELFHIP_EINVAL; }
+  return b->slab->legal_mask(d_mask, d_terminal);
+}
+
+int elfhip_boards_step(elfhip_boards* b, const int16_t* d_actions, uint8_t* d_ok) {
+  CHECK_H(b);
+  if (!d_actions) { elfhip_set_error("boards_step: null d_actions"); return ELFHIP_EINVAL; }
+  return b->slab->step(d_actions, d_ok);
+}
+
+int elfhip_boards_features(elfhip_boards* b, void* d_out, int dtype) {
+  CHECK_H(b);
+  if (!d_out) { elfhip_set_error("boards_features: null d_out"); return ELFHIP_EINVAL; }
+  return b->slab->features(d_out, dtype);
+}
+
+int elfhip_boards_evaluate(elfhip_boards* b, float* d_value) {
+  CHECK_H(b);
+  if (!d_value) { elfhip_set_error("boards_evaluate: null d_value"); return ELFHIP_EINVAL; }
+  return b->slab->evaluate(d_value);
+}
+
+int elfhip_boards_playout(elfhip_boards* b, int nply, uint64_t seed, uint64_t first_board_id,
+                          unsigned long long* d_moves) {
+  CHECK_H(b);
+  if (nply < 0 || nply > (1 << 20)) { elfhip_set_error("boards_playout: nply=%d out of range", nply); return ELFHIP_EINVAL; }
+  if (nply == 0) return ELFHIP_OK;
+  return b->slab->playout(nply, seed, first_board_id, d_moves);
+}
+
+}  // extern "C"

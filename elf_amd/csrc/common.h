@@ -1,0 +1,55 @@
+// Shared host/device helpers for the elfhip library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/elfhip.h"
+
+void elfhip_set_error(const char* fmt, ...);
+
+#define HIPCHECK(x)                                                                         \
+  do {                                                                                      \
+    hipError_t e_ = (x);                                                                    \
+    if (e_ != hipSuccess) {                                                                 \
+      elfhip_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_));    \
+      return ELFHIP_EHIP;                                                                   \
+    }                                                                                       \
+  } while (0)
+
+#define ELF_GOLDEN 0x9E3779B97F4A7C15ull
+
+// splitmix64 counter RNG of SURVEY.md 8(d)
+__host__ __device__ inline uint64_t elf_splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// r mod n for 1 <= n < 2^16, without the 64-bit division routine:
+// r = hi*2^32 + lo  ->  ((hi mod n) * (2^32 mod n) + (lo mod n)) mod n, all in 32 bits.
+__device__ inline uint32_t elf_mod_u64_small(uint64_t r, uint32_t n) {
+  uint32_t hi = (uint32_t)(r >> 32), lo = (uint32_t)r;
+  uint32_t p32 = ((0xFFFFFFFFu % n) + 1u) % n;  // 2^32 mod n in 32-bit arithmetic
+  uint32_t a = hi % n, b = lo % n;
+  return (a * p32 + b) % n;  // a*p32 < 2^32 because a,p32 < 2^16
+}
+
+// Abstract slab of boards; one subclass per game (american.hip, go.hip, ...).
+struct BoardSlab {
+  int game = 0, n = 0, device = 0;
+  hipStream_t stream = nullptr;
+  uint64_t step_counter = 0;  // plies driven by playout() since reset (RNG counter)
+  virtual ~BoardSlab() {}
+  virtual int alloc() = 0;
+  virtual int reset() = 0;
+  virtual int export_states(uint64_t* h) = 0;
+  virtual int import_states(const uint64_t* h) = 0;
+  virtual int legal_mask(uint64_t* d_mask, uint8_t* d_terminal) = 0;
+  virtual int step(const int16_t* d_actions, uint8_t* d_ok) = 0;
+  virtual int features(void* d_out, int dtype) = 0;
+  virtual int evaluate(float* d_value) = 0;
+  virtual int playout(int nply, uint64_t seed, uint64_t first_id, unsigned long long* d_moves) = 0;
+};
+
+BoardSlab* elfhip_make_american();
+BoardSlab* elfhip_make_go19();
