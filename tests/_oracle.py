@@ -59,6 +59,25 @@ def oracle():
         L.am_game_evaluate.argtypes = [C.c_void_p]
         L.am_game_evaluate.restype = C.c_float
         L.am_game_features.argtypes = [C.c_void_p, _f32p]
+        # --- Go (build-defined rules; PARITY UNPINNED vs ELF, see oracle/go.h)
+        L.go_zobrist.argtypes = [C.c_int, C.c_int]
+        L.go_zobrist.restype = C.c_uint64
+        L.go_reset.argtypes = [C.c_void_p]
+        L.go_terminated.argtypes = [C.c_void_p]
+        L.go_terminated.restype = C.c_int
+        L.go_legal_mask.argtypes = [C.c_void_p, _u64p]
+        L.go_forward.argtypes = [C.c_void_p, C.c_int]
+        L.go_forward.restype = C.c_int
+        L.go_evaluate.argtypes = [C.c_void_p]
+        L.go_evaluate.restype = C.c_float
+        L.go_tt_score.argtypes = [C.c_void_p]
+        L.go_tt_score.restype = C.c_float
+        L.go_features.argtypes = [C.c_void_p, _f32p]
+        L.go_export.argtypes = [C.c_void_p, _u64p]
+        L.go_import.argtypes = [C.c_void_p, _u64p]
+        L.go_playout.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]
+        L.go_playout.restype = C.c_uint64
+        L.go_sizeof_state.restype = C.c_int
         _oracle = L
     return _oracle
 
@@ -120,3 +139,100 @@ class AmGame:
 def mask_bits(m, n):
     """u64 words -> list of set bit indices < n"""
     return [i for i in range(n) if (int(m[i >> 6]) >> (i & 63)) & 1]
+
+
+GO_PASS = 361
+GO_NO_POINT = 0xFFFF
+
+
+class GoBoards:
+    """n oracle go_state structs in one buffer."""
+
+    def __init__(self, n=1):
+        self.L = oracle()
+        self.n = n
+        self.sz = self.L.go_sizeof_state()
+        self.buf = C.create_string_buffer(self.sz * n)
+        for i in range(n):
+            self.L.go_reset(self.ptr(i))
+
+    def ptr(self, i=0):
+        return C.c_void_p(C.addressof(self.buf) + i * self.sz)
+
+    def reset(self, i=0):
+        self.L.go_reset(self.ptr(i))
+
+    def forward(self, a, i=0):
+        return bool(self.L.go_forward(self.ptr(i), int(a)))
+
+    def play(self, r, c, i=0):
+        return self.forward(r * 19 + c, i)
+
+    def terminated(self, i=0):
+        return bool(self.L.go_terminated(self.ptr(i)))
+
+    def mask(self, i=0):
+        m = np.zeros(6, dtype=np.uint64)
+        self.L.go_legal_mask(self.ptr(i), m)
+        return m
+
+    def legal(self, i=0):
+        return mask_bits(self.mask(i), 362)
+
+    def export(self, i=0):
+        w = np.zeros(22, dtype=np.uint64)
+        self.L.go_export(self.ptr(i), w)
+        return w
+
+    def export_all(self):
+        return np.stack([self.export(i) for i in range(self.n)])
+
+    def load(self, w, i=0):
+        self.L.go_import(self.ptr(i), np.ascontiguousarray(w, dtype=np.uint64))
+
+    def features(self, i=0):
+        f = np.zeros(18 * 361, dtype=np.float32)
+        self.L.go_features(self.ptr(i), f)
+        return f.reshape(18, 19, 19)
+
+    def score(self, i=0):
+        return float(self.L.go_tt_score(self.ptr(i)))
+
+    def evaluate(self, i=0):
+        return float(self.L.go_evaluate(self.ptr(i)))
+
+    def playout(self, nply, seed=0x5EED0001, board_id0=0, step_base=0):
+        return self.L.go_playout(self.buf, self.n, board_id0, step_base, nply, seed)
+
+
+def go_words_to_grid(w):
+    """export words -> 19x19 int array (0 empty, 1 black, 2 white)"""
+    g = np.zeros((19, 19), dtype=np.int8)
+    for r in range(19):
+        for c in range(19):
+            if (int(w[r]) >> c) & 1:
+                g[r, c] = 1
+            elif (int(w[r]) >> (32 + c)) & 1:
+                g[r, c] = 2
+    return g
+
+
+def go_grid_to_words(g, to_move=0, ply=0):
+    w = np.zeros(22, dtype=np.uint64)
+    for r in range(19):
+        v = 0
+        for c in range(19):
+            if g[r][c] == 1:
+                v |= 1 << c
+            elif g[r][c] == 2:
+                v |= 1 << (32 + c)
+        w[r] = v
+    h = 0
+    L = oracle()
+    for r in range(19):
+        for c in range(19):
+            if g[r][c]:
+                h ^= L.go_zobrist(int(g[r][c]) - 1, r * 19 + c)
+    w[19] = h
+    w[20] = (to_move & 1) | (ply << 16) | (GO_NO_POINT << 32) | (GO_NO_POINT << 48)
+    return w
