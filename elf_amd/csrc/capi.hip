@@ -36,7 +36,7 @@ int elfhip_game_get_info(int game, elfhip_game_info* out) {
   if (!out) { elfhip_set_error("game_get_info: null out"); return ELFHIP_EINVAL; }
   switch (game) {
     case ELFHIP_AMERICAN: *out = {170, 3, 6, 36, 8, 250}; return ELFHIP_OK;
-    case ELFHIP_GO19: *out = {362, 6, 60, 18, 19, 722}; return ELFHIP_OK;
+    case ELFHIP_GO19: *out = {362, 6, 22, 18, 19, 722}; return ELFHIP_OK;
     default: elfhip_set_error("game_get_info: unknown or unbuilt game %d", game); return ELFHIP_EINVAL;
   }
 }

@@ -1,3 +1,530 @@
-// Go 19x19 slab - placeholder until the kernel lands (returns "unbuilt game").
+// Go 19x19 on gfx950.  BUILD-DEFINED rules (the reference fork has no Go source);
+// semantics are those of oracle/go.c, which this file is held bit-exact to.
+//
+// Formulation: one lane owns one board.  A board is 19 row bitmasks per colour held in VGPRs
+// (every row loop is fully unrolled so indices are static and nothing spills to scratch), plus a
+// third bitboard AT = "stones of groups that have exactly one liberty".  AT is maintained
+// incrementally, which makes the whole-board legal mask pure bit arithmetic:
+//     T = empty | (own & ~AT) | (opp & AT)          legal = empty & neighbours(T) & ~ko
+// (a point is playable iff it touches an empty point, an own group that keeps a liberty, or an
+// opponent group in atari).  Groups are found by row-sweep flood fills whose exit is a wave-wide
+// ballot (__any), so all 64 boards of a wavefront iterate together.  Boards are struct-of-arrays
+// in HBM (u32 word w of board b at [w*n + b]) so loads/stores are coalesced 4 B/lane.
+// Positional superko uses a per-board open-addressing table of 1024 x {hash, game generation}
+// in HBM (16 KB/board, sized for 288 GB parts) instead of scanning the move history.
 #include "common.h"
-BoardSlab* elfhip_make_go19() { return nullptr; }
+
+namespace {
+
+constexpr int GN = 19;
+constexpr uint32_t FULL = 0x7FFFFu;
+constexpr int GO_POINTS = 361;
+constexpr int GO_PASS = 361;
+constexpr int GO_MAX_PLY = 722;
+constexpr uint32_t NO_POINT = 0xFFFFu;
+constexpr uint64_t GO_ZSEED = 0x60BA7D5EEDull;
+constexpr int TAB_SLOTS = 1024;
+constexpr int GO_WORDS = 22;
+constexpr int NROWW = 57;  // B[19], W[19], AT[19]
+
+#define ROWS(i) _Pragma("unroll") for (int i = 0; i < GN; ++i)
+#define ROWS_REV(i) _Pragma("unroll") for (int i = GN - 1; i >= 0; --i)
+
+struct GoS {
+  uint32_t P[GN], Q[GN], AT[GN];  // P = stones of the side to move, Q = the other side
+  uint32_t tm, passes, superko, ply, ko, last, capP, capQ;
+  uint64_t hash;
+};
+
+__device__ inline bool go_terminated(const GoS& s) { return s.passes >= 2 || s.ply >= GO_MAX_PLY || s.superko; }
+
+__device__ inline void go_clear(GoS& s) {
+  ROWS(i) { s.P[i] = 0; s.Q[i] = 0; s.AT[i] = 0; }
+  s.tm = 0; s.passes = 0; s.superko = 0; s.ply = 0; s.ko = NO_POINT; s.last = NO_POINT; s.capP = 0; s.capQ = 0;
+  s.hash = 0;
+}
+
+// 4-neighbourhood of a row-bitboard set
+#define NBR(X, i) ((((X)[i] << 1) | ((X)[i] >> 1) | ((i) > 0 ? (X)[(i) > 0 ? (i)-1 : 0] : 0u) | ((i) < GN - 1 ? (X)[(i) < GN - 1 ? (i) + 1 : 0] : 0u)) & FULL)
+
+// Flood fill: grow F (subset of M) to the union of M-connected components it touches.
+// Alternating down/up sweeps, in place; exits when no lane of the wave changed.
+__device__ inline void go_fill(uint32_t (&F)[GN], const uint32_t (&M)[GN]) {
+  for (;;) {
+    uint32_t chg = 0;
+    ROWS(i) {
+      uint32_t up = i > 0 ? F[i > 0 ? i - 1 : 0] : 0u, dn = i < GN - 1 ? F[i < GN - 1 ? i + 1 : 0] : 0u;
+      uint32_t t = (F[i] | up | dn) & M[i];
+      t = (t | (t << 1) | (t >> 1)) & M[i];
+      t = (t | (t << 1) | (t >> 1)) & M[i];
+      chg |= t ^ F[i];
+      F[i] = t;
+    }
+    ROWS_REV(i) {
+      uint32_t up = i > 0 ? F[i > 0 ? i - 1 : 0] : 0u, dn = i < GN - 1 ? F[i < GN - 1 ? i + 1 : 0] : 0u;
+      uint32_t t = (F[i] | up | dn) & M[i];
+      t = (t | (t << 1) | (t >> 1)) & M[i];
+      t = (t | (t << 1) | (t >> 1)) & M[i];
+      chg |= t ^ F[i];
+      F[i] = t;
+    }
+    if (!__any(chg != 0)) break;
+  }
+}
+
+__device__ inline bool go_any_rows(const uint32_t (&X)[GN]) {
+  uint32_t o = 0;
+  ROWS(i) o |= X[i];
+  return __any(o != 0);
+}
+
+// number of liberties of the stone set G (empty points adjacent to it)
+__device__ inline int go_libs(const uint32_t (&G)[GN], const GoS& s) {
+  int n = 0;
+  ROWS(i) {
+    uint32_t e = ~(s.P[i] | s.Q[i]) & FULL;
+    n += __popc(NBR(G, i) & e);
+  }
+  return n;
+}
+
+__device__ inline void go_set_at(GoS& s, const uint32_t (&G)[GN], bool in_atari) {
+  ROWS(i) s.AT[i] = (s.AT[i] & ~G[i]) | (in_atari ? G[i] : 0u);
+}
+
+// whole-board legal point mask for the side to move
+__device__ inline int go_legal_rows(const GoS& s, uint32_t (&L)[GN]) {
+  uint32_t T[GN], E[GN];
+  ROWS(i) {
+    E[i] = ~(s.P[i] | s.Q[i]) & FULL;
+    T[i] = E[i] | (s.P[i] & ~s.AT[i]) | (s.Q[i] & s.AT[i]);
+  }
+  const uint32_t kr = s.ko == NO_POINT ? 99u : s.ko / 19u, kb = s.ko == NO_POINT ? 0u : 1u << (s.ko % 19u);
+  int n = 0;
+  ROWS(i) {
+    uint32_t l = E[i] & NBR(T, i);
+    l &= ~((uint32_t)i == kr ? kb : 0u);
+    L[i] = l;
+    n += __popc(l);
+  }
+  return n;
+}
+
+// Play a stone for the side to move at row r / column bit `bit` (must be legal) when act is true;
+// lanes with act == false run the same instructions with empty seeds and change nothing.
+// Updates stones, AT, hash, ko, capP.  z = Zobrist table in LDS ([colour*361 + point]).
+__device__ inline void go_place(GoS& s, bool act, uint32_t r, uint32_t bit, const uint64_t* z) {
+  if (!act) bit = 0;
+  uint32_t C[GN];  // captured stones
+  uint32_t ncap = 0, cap_pt = 0;
+  uint32_t own_size = 0, own_libs = 0;
+  // jobs: 0 capture (opp groups in atari next to the stone), 1 release (own atari groups next to
+  // captured stones gain liberties), 2 own group of the new stone, 3..6 opp neighbour groups
+#pragma unroll 1
+  for (int job = 0; job < 7; ++job) {
+    uint32_t F[GN];
+    const bool onP = (job == 1 || job == 2);
+    if (job == 0) {
+      ROWS(i) {
+        uint32_t s0 = (uint32_t)i == r ? bit : 0u, su = (uint32_t)i + 1 == r ? bit : 0u, sd = (uint32_t)i == r + 1 ? bit : 0u;
+        F[i] = (((s0 << 1) | (s0 >> 1) | su | sd) & FULL) & s.Q[i] & s.AT[i];
+      }
+    } else if (job == 1) {
+      if (!__any(ncap != 0)) continue;
+      ROWS(i) F[i] = NBR(C, i) & s.P[i] & s.AT[i];
+    } else if (job == 2) {
+      ROWS(i) { uint32_t s0 = (uint32_t)i == r ? bit : 0u; s.P[i] |= s0; F[i] = s0; }
+      if (act) s.hash ^= z[s.tm * GO_POINTS + r * 19 + (__ffs(bit) - 1)];
+    } else {
+      const int d = job - 3;  // 0 up, 1 down, 2 left, 3 right
+      ROWS(i) {
+        uint32_t sd;
+        if (d == 0) sd = (uint32_t)i + 1 == r ? bit : 0u;
+        else if (d == 1) sd = (uint32_t)i == r + 1 ? bit : 0u;
+        else if (d == 2) sd = (uint32_t)i == r ? (bit >> 1) : 0u;
+        else sd = (uint32_t)i == r ? ((bit << 1) & FULL) : 0u;
+        F[i] = sd & s.Q[i];
+      }
+    }
+    if (!go_any_rows(F)) {
+      if (job == 0) { ROWS(i) C[i] = 0; }
+      continue;
+    }
+    if (onP) go_fill(F, s.P); else go_fill(F, s.Q);
+    if (job == 0) {
+      ROWS(i) {
+        C[i] = F[i];
+        s.Q[i] &= ~F[i];
+        s.AT[i] &= ~F[i];
+        ncap += __popc(F[i]);
+        if (F[i]) cap_pt = i * 19 + (__ffs(F[i]) - 1);
+        uint32_t m = F[i];
+        while (__any(m != 0)) {
+          if (m) { int c = __ffs(m) - 1; m &= m - 1; s.hash ^= z[(s.tm ^ 1) * GO_POINTS + i * 19 + c]; }
+        }
+      }
+    } else if (job == 1) {
+      ROWS(i) s.AT[i] &= ~F[i];
+    } else {
+      int libs = go_libs(F, s);
+      go_set_at(s, F, libs == 1);
+      if (job == 2) {
+        own_libs = libs;
+        ROWS(i) own_size += __popc(F[i]);
+      }
+    }
+  }
+  if (act) {
+    s.capP += ncap;
+    s.ko = (ncap == 1 && own_size == 1 && own_libs == 1) ? cap_pt : NO_POINT;
+  }
+}
+
+// positional superko set: returns 1 if h was already present, else inserts it
+__device__ inline uint32_t go_table_test_and_insert(ulonglong2* tab, uint64_t gen, uint64_t h) {
+  uint32_t idx = (uint32_t)(h >> 40) & (TAB_SLOTS - 1);
+  for (int probe = 0; probe < TAB_SLOTS; ++probe) {
+    ulonglong2 e = tab[idx];
+    if (e.y != gen) { tab[idx] = make_ulonglong2(h, gen); return 0; }
+    if (e.x == h) return 1;
+    idx = (idx + 1) & (TAB_SLOTS - 1);
+  }
+  return 0;
+}
+
+// One full forward() for this lane's board: a = point index or GO_PASS; act = lane takes part.
+// The caller has verified legality.  Swaps P/Q so that P is again the side to move.
+__device__ inline void go_forward(GoS& s, bool act, uint32_t a, ulonglong2* tab, uint64_t gen, const uint64_t* z) {
+  const bool is_pass = a >= GO_POINTS;
+  const bool pt_move = act && !is_pass;
+  const uint32_t r = pt_move ? a / 19u : 0u, bit = pt_move ? 1u << (a % 19u) : 0u;
+  go_place(s, pt_move, r, bit, z);
+  if (act) {
+    if (is_pass) { s.passes += 1; s.ko = NO_POINT; }
+    else { s.passes = 0; s.superko = go_table_test_and_insert(tab, gen, s.hash); }
+    s.ply += 1; s.last = a; s.tm ^= 1;
+    ROWS(i) { uint32_t t = s.P[i]; s.P[i] = s.Q[i]; s.Q[i] = t; }
+    uint32_t t = s.capP; s.capP = s.capQ; s.capQ = t;
+  }
+}
+
+// ---- SoA storage: rows [57][n] (B, W, AT), meta [4][n], hash [n], gen [n], table [n][1024] -------
+struct GoDev {
+  uint32_t* rows; uint32_t* meta; uint64_t* hash; uint64_t* gen; ulonglong2* table; int n;
+};
+
+__device__ inline void go_load(const GoDev& d, int b, GoS& s) {
+  const size_t n = d.n;
+  uint32_t m0 = d.meta[0 * n + b], m1 = d.meta[1 * n + b];
+  s.tm = m0 & 1; s.passes = (m0 >> 1) & 3; s.superko = (m0 >> 3) & 1; s.ply = m0 >> 16;
+  s.ko = m1 & 0xFFFF; s.last = m1 >> 16;
+  uint32_t cb = d.meta[2 * n + b], cw = d.meta[3 * n + b];
+  s.capP = s.tm ? cw : cb; s.capQ = s.tm ? cb : cw;
+  s.hash = d.hash[b];
+  ROWS(i) {
+    uint32_t bl = d.rows[(size_t)i * n + b], wh = d.rows[(size_t)(19 + i) * n + b];
+    s.P[i] = s.tm ? wh : bl; s.Q[i] = s.tm ? bl : wh;
+    s.AT[i] = d.rows[(size_t)(38 + i) * n + b];
+  }
+}
+
+__device__ inline void go_store(const GoDev& d, int b, const GoS& s) {
+  const size_t n = d.n;
+  d.meta[0 * n + b] = s.tm | (s.passes << 1) | (s.superko << 3) | (s.ply << 16);
+  d.meta[1 * n + b] = (s.ko & 0xFFFF) | (s.last << 16);
+  d.meta[2 * n + b] = s.tm ? s.capQ : s.capP;
+  d.meta[3 * n + b] = s.tm ? s.capP : s.capQ;
+  d.hash[b] = s.hash;
+  ROWS(i) {
+    d.rows[(size_t)i * n + b] = s.tm ? s.Q[i] : s.P[i];
+    d.rows[(size_t)(19 + i) * n + b] = s.tm ? s.P[i] : s.Q[i];
+    d.rows[(size_t)(38 + i) * n + b] = s.AT[i];
+  }
+}
+
+__device__ inline void go_load_zobrist(uint64_t* z, const uint64_t* gz) {
+  for (int i = threadIdx.x; i < 2 * GO_POINTS; i += blockDim.x) z[i] = gz[i];
+  __syncthreads();
+}
+
+// AT from scratch (import): label every group of both colours
+__device__ inline void go_recompute_at(GoS& s) {
+  ROWS(i) s.AT[i] = 0;
+#pragma unroll 1
+  for (int col = 0; col < 2; ++col) {
+    uint32_t rem[GN];
+    ROWS(i) rem[i] = col ? s.Q[i] : s.P[i];
+    while (go_any_rows(rem)) {
+      uint32_t F[GN];
+      bool found = false;
+      ROWS(i) {
+        uint32_t lb = rem[i] & (0u - rem[i]);
+        F[i] = found ? 0u : lb;
+        found = found || rem[i] != 0;
+      }
+      if (col) go_fill(F, s.Q); else go_fill(F, s.P);
+      int libs = go_libs(F, s);
+      ROWS(i) { s.AT[i] |= (libs == 1) ? F[i] : 0u; rem[i] &= ~F[i]; }
+    }
+  }
+}
+
+// ---- kernels ------------------------------------------------------------------------------------
+__global__ void go_zobrist_init_kernel(uint64_t* gz) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * GO_POINTS) gz[i] = elf_splitmix64(GO_ZSEED + (uint64_t)i);
+}
+
+__global__ void __launch_bounds__(64) go_reset_kernel(GoDev d) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= d.n) return;
+  GoS s; go_clear(s);
+  go_store(d, b, s);
+  uint64_t gen = d.gen[b] + 1;
+  d.gen[b] = gen;
+  go_table_test_and_insert(d.table + (size_t)b * TAB_SLOTS, gen, 0);  // the empty start position
+}
+
+__global__ void __launch_bounds__(64) go_import_kernel(GoDev d, const uint64_t* __restrict__ aos) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = b < d.n;
+  GoS s; go_clear(s);
+  if (valid) {
+    const uint64_t* w = aos + (size_t)b * GO_WORDS;
+    uint64_t m = w[20];
+    s.tm = m & 1; s.passes = (m >> 1) & 3; s.superko = (m >> 3) & 1; s.ply = (m >> 16) & 0xFFFF;
+    s.ko = (m >> 32) & 0xFFFF; s.last = (m >> 48) & 0xFFFF;
+    uint32_t cb = (uint32_t)w[21], cw = (uint32_t)(w[21] >> 32);
+    s.capP = s.tm ? cw : cb; s.capQ = s.tm ? cb : cw;
+    s.hash = w[19];
+    ROWS(i) {
+      uint32_t bl = (uint32_t)w[i] & FULL, wh = (uint32_t)(w[i] >> 32) & FULL;
+      s.P[i] = s.tm ? wh : bl; s.Q[i] = s.tm ? bl : wh;
+    }
+  }
+  go_recompute_at(s);
+  if (valid) {
+    go_store(d, b, s);
+    uint64_t gen = d.gen[b] + 1;
+    d.gen[b] = gen;
+    go_table_test_and_insert(d.table + (size_t)b * TAB_SLOTS, gen, s.hash);
+  }
+}
+
+__global__ void __launch_bounds__(64) go_export_kernel(GoDev d, uint64_t* __restrict__ aos) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= d.n) return;
+  GoS s; go_load(d, b, s);
+  uint64_t* w = aos + (size_t)b * GO_WORDS;
+  ROWS(i) {
+    uint32_t bl = s.tm ? s.Q[i] : s.P[i], wh = s.tm ? s.P[i] : s.Q[i];
+    w[i] = (uint64_t)bl | ((uint64_t)wh << 32);
+  }
+  w[19] = s.hash;
+  w[20] = (uint64_t)s.tm | ((uint64_t)s.passes << 1) | ((uint64_t)s.superko << 3) | ((uint64_t)s.ply << 16) |
+          ((uint64_t)(s.ko & 0xFFFF) << 32) | ((uint64_t)(s.last & 0xFFFF) << 48);
+  uint32_t cb = s.tm ? s.capQ : s.capP, cw = s.tm ? s.capP : s.capQ;
+  w[21] = (uint64_t)cb | ((uint64_t)cw << 32);
+}
+
+// rows -> 362-bit action mask (bit r*19+c; bit 361 = pass)
+__device__ inline void go_pack_mask(const uint32_t (&L)[GN], bool alive, uint64_t (&m)[6]) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) m[k] = 0;
+  ROWS(i) {
+    const int base = i * 19, w = base >> 6, o = base & 63;
+    uint64_t v = alive ? (uint64_t)L[i] : 0ull;
+    m[w] |= v << o;
+    if (o + 19 > 64) m[w + 1] |= v >> (64 - o);
+  }
+  if (alive) m[GO_PASS >> 6] |= 1ull << (GO_PASS & 63);
+}
+
+__global__ void __launch_bounds__(64) go_mask_kernel(GoDev d, uint64_t* __restrict__ mask, uint8_t* __restrict__ term) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= d.n) return;
+  GoS s; go_load(d, b, s);
+  uint32_t L[GN];
+  go_legal_rows(s, L);
+  uint64_t m[6];
+  const bool alive = !go_terminated(s);
+  go_pack_mask(L, alive, m);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) mask[(size_t)b * 6 + k] = m[k];
+  if (term) term[b] = alive ? 0 : 1;
+}
+
+__global__ void __launch_bounds__(64) go_step_kernel(GoDev d, const uint64_t* __restrict__ gz,
+                                                     const int16_t* __restrict__ actions, uint8_t* __restrict__ ok) {
+  __shared__ uint64_t z[2 * GO_POINTS];
+  go_load_zobrist(z, gz);
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = b < d.n;
+  GoS s; go_clear(s);
+  int a = -1;
+  if (valid) { go_load(d, b, s); a = actions[b]; }
+  bool good = valid && a >= 0 && a <= GO_PASS && !go_terminated(s);
+  uint32_t L[GN];
+  go_legal_rows(s, L);
+  if (good && a < GO_POINTS) {
+    uint32_t r = (uint32_t)a / 19u, c = (uint32_t)a % 19u, row = 0;
+    ROWS(i) row = (uint32_t)i == r ? L[i] : row;
+    good = (row >> c) & 1;
+  }
+  uint64_t gen = valid ? d.gen[b] : 0;
+  go_forward(s, good, (uint32_t)(a < 0 ? 0 : a), d.table + (size_t)(valid ? b : 0) * TAB_SLOTS, gen, z);
+  if (good) go_store(d, b, s);
+  if (valid && ok) ok[b] = good ? 1 : 0;
+}
+
+// Random-legal playouts: nply steps per launch with the board in registers.
+__global__ void __launch_bounds__(64)
+go_playout_kernel(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t seed, uint64_t first_id,
+                  uint64_t step_base, unsigned long long* __restrict__ moves_out) {
+  __shared__ uint64_t z[2 * GO_POINTS];
+  go_load_zobrist(z, gz);
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = b < d.n;
+  GoS s; go_clear(s);
+  uint64_t gen = 0;
+  ulonglong2* tab = d.table + (size_t)(valid ? b : 0) * TAB_SLOTS;
+  if (valid) { go_load(d, b, s); gen = d.gen[b]; }
+  const uint64_t key = seed + (first_id + (uint64_t)b) * ELF_GOLDEN + step_base;
+  unsigned long long moves = 0;
+#pragma unroll 1
+  for (int step = 0; step < nply; ++step) {
+    const bool term = go_terminated(s);
+    if (valid && term) {  // reset in place, 0 moves
+      go_clear(s);
+      gen += 1;
+      go_table_test_and_insert(tab, gen, 0);
+    }
+    const bool act = valid && !term;
+    uint32_t L[GN];
+    int n = go_legal_rows(s, L);
+    uint32_t a = GO_PASS;
+    if (act && n > 0) {
+      uint64_t r = elf_splitmix64(key + (uint64_t)step);
+      int k = (int)elf_mod_u64_small(r, (uint32_t)n);
+      uint32_t row = 0, rowbits = 0;
+      bool found = false;
+      ROWS(i) {
+        int c = __popc(L[i]);
+        bool here = !found && k < c;
+        if (here) { row = i; rowbits = L[i]; found = true; }
+        if (!found) k -= c;
+      }
+      for (int j = 0; j < k; ++j) rowbits &= rowbits - 1;
+      a = row * 19 + (uint32_t)(__ffs(rowbits) - 1);
+    }
+    go_forward(s, act, a, tab, gen, z);
+    moves += act ? 1 : 0;
+  }
+  if (valid) { go_store(d, b, s); d.gen[b] = gen; }
+  if (moves_out) {
+    for (int o = 32; o > 0; o >>= 1) moves += __shfl_down(moves, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(moves_out, moves);
+  }
+}
+
+// Tromp-Taylor area score, komi 7.5 (oracle/go.c go_tt_score); value = 0 unless terminated
+__global__ void __launch_bounds__(64) go_evaluate_kernel(GoDev d, float* __restrict__ value, float* __restrict__ score) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = b < d.n;
+  GoS s; go_clear(s);
+  if (valid) go_load(d, b, s);
+  uint32_t E[GN], RP[GN], RQ[GN];
+  ROWS(i) E[i] = ~(s.P[i] | s.Q[i]) & FULL;
+  ROWS(i) { RP[i] = NBR(s.P, i) & E[i]; RQ[i] = NBR(s.Q, i) & E[i]; }
+  go_fill(RP, E);
+  go_fill(RQ, E);
+  int ap = 0, aq = 0;
+  ROWS(i) { ap += __popc(s.P[i]) + __popc(RP[i] & ~RQ[i]); aq += __popc(s.Q[i]) + __popc(RQ[i] & ~RP[i]); }
+  int black = s.tm ? aq : ap, white = s.tm ? ap : aq;
+  float sc = (float)black - (float)white - 7.5f;
+  if (valid) {
+    if (score) score[b] = sc;
+    if (value) value[b] = go_terminated(s) ? (sc > 0 ? 1.f : -1.f) : 0.f;
+  }
+}
+
+struct GoSlab : BoardSlab {
+  GoDev d{};
+  uint64_t* gz = nullptr;   // Zobrist table [2*361]
+  uint64_t* aos = nullptr;  // [n][22] staging
+  ~GoSlab() override {
+    (void)hipFree(d.rows); (void)hipFree(d.meta); (void)hipFree(d.hash); (void)hipFree(d.gen);
+    (void)hipFree(d.table); (void)hipFree(gz); (void)hipFree(aos);
+  }
+  int grid() const { return (n + 63) / 64; }
+  int alloc() override {
+    d.n = n;
+    size_t N = (size_t)n;
+    if (hipMalloc(&d.rows, sizeof(uint32_t) * NROWW * N) != hipSuccess ||
+        hipMalloc(&d.meta, sizeof(uint32_t) * 4 * N) != hipSuccess ||
+        hipMalloc(&d.hash, sizeof(uint64_t) * N) != hipSuccess ||
+        hipMalloc(&d.gen, sizeof(uint64_t) * N) != hipSuccess ||
+        hipMalloc(&d.table, sizeof(ulonglong2) * TAB_SLOTS * N) != hipSuccess ||
+        hipMalloc(&gz, sizeof(uint64_t) * 2 * GO_POINTS) != hipSuccess ||
+        hipMalloc(&aos, sizeof(uint64_t) * GO_WORDS * N) != hipSuccess) {
+      elfhip_set_error("go19: device allocation of %d boards failed (needs %.1f MB)", n,
+                       (double)N * (sizeof(ulonglong2) * TAB_SLOTS + 600) / 1e6);
+      return ELFHIP_ENOMEM;
+    }
+    HIPCHECK(hipMemsetAsync(d.gen, 0, sizeof(uint64_t) * N, stream));
+    HIPCHECK(hipMemsetAsync(d.table, 0, sizeof(ulonglong2) * TAB_SLOTS * N, stream));
+    hipLaunchKernelGGL(go_zobrist_init_kernel, dim3(3), dim3(256), 0, stream, gz);
+    HIPCHECK(hipGetLastError());
+    return reset();
+  }
+  int reset() override {
+    step_counter = 0;
+    hipLaunchKernelGGL(go_reset_kernel, dim3(grid()), dim3(64), 0, stream, d);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  int export_states(uint64_t* h) override {
+    hipLaunchKernelGGL(go_export_kernel, dim3(grid()), dim3(64), 0, stream, d, aos);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(h, aos, sizeof(uint64_t) * GO_WORDS * (size_t)n, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    return ELFHIP_OK;
+  }
+  int import_states(const uint64_t* h) override {
+    HIPCHECK(hipMemcpyAsync(aos, h, sizeof(uint64_t) * GO_WORDS * (size_t)n, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(go_import_kernel, dim3(grid()), dim3(64), 0, stream, d, aos);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(stream));
+    return ELFHIP_OK;
+  }
+  int legal_mask(uint64_t* d_mask, uint8_t* d_terminal) override {
+    hipLaunchKernelGGL(go_mask_kernel, dim3(grid()), dim3(64), 0, stream, d, d_mask, d_terminal);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  int step(const int16_t* d_actions, uint8_t* d_ok) override {
+    hipLaunchKernelGGL(go_step_kernel, dim3(grid()), dim3(64), 0, stream, d, gz, d_actions, d_ok);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  int features(void*, int) override {
+    elfhip_set_error("go19 features: not built yet");
+    return ELFHIP_ESTATE;
+  }
+  int evaluate(float* d_value) override {
+    hipLaunchKernelGGL(go_evaluate_kernel, dim3(grid()), dim3(64), 0, stream, d, d_value, (float*)nullptr);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  int playout(int nply, uint64_t seed, uint64_t first_id, unsigned long long* d_moves) override {
+    hipLaunchKernelGGL(go_playout_kernel, dim3(grid()), dim3(64), 0, stream, d, gz, nply, seed, first_id,
+                       step_counter, d_moves);
+    HIPCHECK(hipGetLastError());
+    step_counter += (uint64_t)nply;
+    return ELFHIP_OK;
+  }
+};
+
+}  // namespace
+
+BoardSlab* elfhip_make_go19() { return new GoSlab(); }
