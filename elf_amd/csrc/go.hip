@@ -50,6 +50,7 @@ __device__ inline void go_clear(GoS& s) {
 // Flood fill: grow F (subset of M) to the union of M-connected components it touches.
 // Alternating down/up sweeps, in place; exits when no lane of the wave changed.
 __device__ inline void go_fill(uint32_t (&F)[GN], const uint32_t (&M)[GN]) {
+  // A complete sweep that changes nothing proves a fixpoint, so test after every sweep.
   for (;;) {
     uint32_t chg = 0;
     ROWS(i) {
@@ -60,6 +61,8 @@ __device__ inline void go_fill(uint32_t (&F)[GN], const uint32_t (&M)[GN]) {
       chg |= t ^ F[i];
       F[i] = t;
     }
+    if (!__any(chg != 0)) break;
+    chg = 0;
     ROWS_REV(i) {
       uint32_t up = i > 0 ? F[i > 0 ? i - 1 : 0] : 0u, dn = i < GN - 1 ? F[i < GN - 1 ? i + 1 : 0] : 0u;
       uint32_t t = (F[i] | up | dn) & M[i];
