@@ -1,0 +1,271 @@
+// TEST INFRASTRUCTURE ONLY (oracle).  CPU restatement of the reference's tree search for American
+// checkers, num_threads = 1:
+//   elf/ai/tree_search/tree_search.h:112-152,241-378 (run / batch_rollouts / single_rollout),
+//   tree_search_node.h:98-422,436-609 (NodeT, TreeT), tree_search_base.h:137-216,284-367
+//   (EdgeInfo::getScore, MCTSResultT::addActions), mcts.h:81-105,167-202 (act / align_state),
+//   elfgames/american_checkers/mcts/MCTSGameActor.h:198-335 (pre_evaluate, pi2response).
+// The reference headers cannot be compiled here (spdlog / nlohmann-json / tbb / concurrentqueue
+// are un-vendored), so this is a restatement, pinned by the known answers the survey captured
+// from the compiled reference (tests/golden/mcts_appendix_c.json).
+// It deliberately uses the SAME libstdc++ containers as the reference (std::unordered_map for the
+// edges, std::sort for pi) so iteration order and tie-breaking are the library's own; the HIP
+// path re-implements both orders explicitly and is checked against this.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "american.h"
+
+namespace {
+
+using Action = unsigned short;  // Coord, GameBoard.h:51
+
+struct TsOptions {  // TSOptions / SearchAlgoOptions, tree_search_options.h:24-29,91-110
+  int num_rollouts;            // num_rollouts_per_thread (num_threads == 1)
+  int num_rollouts_per_batch;
+  int virtual_loss;
+  int use_prior;
+  float c_puct;
+  int unexplored_q_zero, root_unexplored_q_zero;
+  int persistent_tree;
+  int pick_method;             // 0 most_visited, 1 strongest_prior
+};
+
+struct Edge {  // EdgeInfo tree_search_base.h:137-159
+  float prior; int child; float reward; int num_visits; float virtual_loss;
+  explicit Edge(float p) : prior(p), child(-1), reward(0), num_visits(0), virtual_loss(0) {}
+};
+
+struct Node {  // NodeT tree_search_node.h:98-115,323-334
+  int status = 0;  // 0 NOT_VISITED, 1 EVAL_REQUESTED, 2 VISITED
+  int numVisits = 0;
+  float V = 0.f, meanQ = 0.f, parentQ = 0.f;
+  bool flip = false;
+  std::unordered_map<Action, Edge> edges;
+  std::unique_ptr<am_game> state;
+  explicit Node(float pq) : meanQ(pq), parentQ(pq) {}
+};
+
+struct Response { std::vector<std::pair<Action, float>> pi; float value = 0; bool q_flip = false; };
+
+uint64_t state_hash(const am_state& b) {
+  uint64_t h = 0x1234567ull;
+  for (int i = 0; i < 6; ++i) h = elf_splitmix64(h ^ b.w[i]);
+  return h;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Scripted network stand-in: pi on a 2^-10 grid (ties do occur), V on a 2^-10 grid in (-1,1), so
+// every float sum in the search is exact and the result is independent of backup order.
+void omcts_scripted_policy(const uint64_t* board6, uint64_t seed, float* pi170, float* v) {
+  am_state b; memcpy(b.w, board6, sizeof(b.w));
+  uint64_t h = state_hash(b) ^ seed;
+  for (int i = 0; i < AM_NUM_ACTIONS; ++i) {
+    uint64_t r = elf_splitmix64(h + (uint64_t)i);
+    pi170[i] = (float)((r & 1023) + 1) / 1024.0f;
+  }
+  uint64_t r = elf_splitmix64(h + 1000);
+  *v = ((float)(r & 2047) - 1024.0f) / 1024.0f;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct Mcts {
+  TsOptions opt;
+  int policy_kind;  // 0 uniform (pi = 1/170, V = 0), 1 scripted
+  uint64_t policy_seed;
+  std::unordered_map<int, std::unique_ptr<Node>> nodes;  // TreeT::allocatedNodes_
+  int next_id = 0, root = -1;
+  long evals = 0, rollouts = 0, depth_sum = 0, edge_sum = 0;
+
+  Mcts() { clear(); }
+  int add_node(float pq) { nodes[next_id].reset(new Node(pq)); return next_id++; }
+  void clear() { nodes.clear(); next_id = 0; root = -1; root = add_node(0.f); }  // TreeT::clear
+  Node* get(int id) { auto it = nodes.find(id); return it == nodes.end() ? nullptr : it->second.get(); }
+
+  void recursive_free(int id) {  // tree_search_node.h:497-507
+    if (id < 0) return;
+    Node* n = get(id);
+    for (auto& p : n->edges) recursive_free(p.second.child);
+    nodes.erase(id);
+  }
+  void tree_advance(Action a) {  // :458-474
+    int next = -1;
+    Node* r = get(root);
+    for (auto& p : r->edges) { if (p.first == a) next = p.second.child; else recursive_free(p.second.child); }
+    nodes.erase(root);
+    root = next;
+    if (root < 0) root = add_node(0.f);
+  }
+
+  // MCTSGameActor.h:198-218 + :256-335
+  void evaluate(const am_game& s, Response* resp) {
+    resp->q_flip = (s.board.w[4] & 1) == 1;
+    resp->pi.clear();
+    if (am_game_terminated(&s)) { resp->value = am_game_evaluate(&s) > 0 ? 1.0f : -1.0f; return; }
+    ++evals;
+    float pi[AM_NUM_ACTIONS], v = 0.f;
+    if (policy_kind == 0) { for (int i = 0; i < AM_NUM_ACTIONS; ++i) pi[i] = 1.0f / 170.0f; }
+    else omcts_scripted_policy(s.board.w, policy_seed, pi, &v);
+    resp->value = v;
+    std::vector<std::pair<Action, float>> all;
+    for (int i = 0; i < AM_NUM_ACTIONS; ++i) all.push_back(std::make_pair((Action)i, pi[i]));
+    using dt = std::pair<Action, float>;
+    std::sort(all.begin(), all.end(), [](const dt& a, const dt& b) { return a.second > b.second; });
+    uint64_t m[3]; am_legal_mask(&s.board, m);
+    for (auto& p : all) if ((m[p.first >> 6] >> (p.first & 63)) & 1) resp->pi.push_back(p);
+    float total = 1e-10;
+    for (auto& p : resp->pi) total += p.second;
+    for (auto& p : resp->pi) p.second /= total;
+  }
+
+  // tree_search_node.h:218-244 + UCT :385-421 + getScore tree_search_base.h:175-201
+  bool find_move(Node* n, int depth, Action* out) {
+    if (n->status != 2 || n->edges.empty()) return false;
+    if (opt.unexplored_q_zero || (opt.root_unexplored_q_zero && depth == 0)) n->meanQ = 0.0f;
+    float best = std::numeric_limits<float>::lowest(), total_uq = 0.f;
+    Action besta = 0; int total_visits = 0;
+    const int all_visits = n->numVisits + 1;
+    for (const auto& ap : n->edges) {
+      const Edge& e = ap.second;
+      float r = e.reward;
+      if (n->flip) r = -r;
+      r -= e.virtual_loss;
+      const int nvl = e.num_visits + e.virtual_loss;   // float add, truncation to int
+      float q = nvl > 0 ? r / nvl : (n->flip ? -n->meanQ : n->meanQ);
+      float uq = e.num_visits > 0 ? e.reward / e.num_visits : n->meanQ;
+      float pp = e.prior / (1 + e.num_visits) * std::sqrt(all_visits);  // double sqrt, one rounding
+      float score = opt.use_prior ? (pp * opt.c_puct + q) : q;
+      if (score > best) { best = score; besta = ap.first; }
+      if (nvl != 0) { total_uq += uq; total_visits++; }
+    }
+    *out = besta;
+    n->meanQ = (n->parentQ + total_uq) / (total_visits + 1);
+    return true;
+  }
+
+  struct Traj { std::vector<std::pair<Node*, Action>> traj; Node* leaf; };
+
+  Traj single_rollout(Node* rootn) {  // tree_search.h:319-378
+    Node* node = rootn; Traj t; int depth = 0;
+    while (node->status == 2) {
+      Action a;
+      if (!find_move(node, depth, &a)) break;
+      Edge& e = node->edges.find(a)->second;
+      if (opt.virtual_loss > 0) e.virtual_loss += (float)opt.virtual_loss;
+      t.traj.push_back(std::make_pair(node, a));
+      if (e.child < 0) e.child = add_node(node->meanQ);  // followEdge :295-317
+      Node* next = get(e.child);
+      if (!next) break;
+      if (!next->state) {  // allocateState tree_search.h:209-224
+        std::unique_ptr<am_game> st(new am_game(*node->state));
+        if (!am_game_forward(st.get(), a)) break;  // NODE_STATE_INVALID (cannot happen: edges are legal)
+        next->state = std::move(st);
+      }
+      node = next; ++depth;
+    }
+    t.leaf = node;
+    depth_sum += depth; ++rollouts;
+    return t;
+  }
+
+  void batch_rollouts(Node* rootn) {  // tree_search.h:241-308
+    std::vector<Traj> trajs;
+    for (int j = 0; j < opt.num_rollouts_per_batch; ++j) trajs.push_back(single_rollout(rootn));
+    std::vector<Node*> locked;
+    // first-trajectory + count per distinct leaf, kept in first-seen order (the reference walks an
+    // unordered_map keyed by Node*; order only matters for float sums, exact in our parity configs)
+    std::vector<std::pair<Node*, std::pair<Traj*, int>>> counts;
+    for (Traj& t : trajs) {
+      if (t.leaf->status == 0) { t.leaf->status = 1; locked.push_back(t.leaf); }
+      bool seen = false;
+      for (auto& c : counts) if (c.first == t.leaf) { c.second.second++; seen = true; break; }
+      if (!seen) counts.push_back(std::make_pair(t.leaf, std::make_pair(&t, 1)));
+    }
+    for (Node* leaf : locked) {
+      Response r; evaluate(*leaf->state, &r);
+      for (auto& ap : r.pi) leaf->edges.insert(std::make_pair(ap.first, Edge(ap.second)));  // setEvaluation :188-215
+      edge_sum += (long)r.pi.size();
+      leaf->V = r.value; leaf->flip = r.q_flip; leaf->status = 2;
+    }
+    for (auto& c : counts) {
+      float reward = c.first->V;
+      int count = c.second.second;
+      for (auto& p : c.second.first->traj) {  // updateEdgeStats :267-292
+        Edge& e = p.first->edges.find(p.second)->second;
+        p.first->numVisits++;
+        e.reward += reward; e.num_visits++;
+        e.virtual_loss -= (float)(opt.virtual_loss * count);
+      }
+    }
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+void* omcts_create(const int* iopt, float c_puct, int policy_kind, uint64_t policy_seed) {
+  Mcts* m = new Mcts();
+  m->opt = TsOptions{iopt[0], iopt[1], iopt[2], iopt[3], c_puct, iopt[4], iopt[5], iopt[6], iopt[7]};
+  m->policy_kind = policy_kind; m->policy_seed = policy_seed;
+  return m;
+}
+void omcts_destroy(void* h) { delete (Mcts*)h; }
+void omcts_clear(void* h) { ((Mcts*)h)->clear(); }                       // MCTSAI_T::resetTree / endGame
+void omcts_advance(void* h, int action) { ((Mcts*)h)->tree_advance((Action)action); }  // advanceMoves
+void omcts_stats(void* h, long* out4) { Mcts* m = (Mcts*)h; out4[0] = m->rollouts; out4[1] = m->evals; out4[2] = m->depth_sum; out4[3] = m->edge_sum; }
+
+// MCTSAI_T::act -> TreeSearchT::run + chooseAction.  Edges are reported in the unordered_map's
+// iteration order.  Returns best action (most_visited: first strict max in that order).
+int omcts_run(void* h, const am_game* g, int max_edges, int* n_edges, uint16_t* actions, int* visits,
+              float* rewards, float* priors, int* total_visits, float* root_value, float* best_q) {
+  Mcts* m = (Mcts*)h;
+  if (!m->opt.persistent_tree) m->clear();
+  Node* rootn = m->get(m->root);
+  if (!rootn->state) rootn->state.reset(new am_game(*g));   // setRootNodeState
+  if (memcmp(rootn->state->board.w, g->board.w, sizeof(g->board.w)) != 0) return -2;  // "Root state is not the same"
+  for (int idx = 0; idx < m->opt.num_rollouts; idx += m->opt.num_rollouts_per_batch) m->batch_rollouts(rootn);
+  // MCTSResultT::addActions tree_search_base.h:310-367
+  float max_score = std::numeric_limits<float>::lowest();
+  int best = 0, tv = 0, k = 0; const Edge* beste = nullptr;
+  for (const auto& ap : rootn->edges) {
+    float score = m->opt.pick_method == 0 ? (float)ap.second.num_visits : ap.second.prior;
+    if (k < max_edges) { actions[k] = ap.first; visits[k] = ap.second.num_visits; rewards[k] = ap.second.reward; priors[k] = ap.second.prior; }
+    ++k;
+    tv += ap.second.num_visits;
+    if (score > max_score) { max_score = score; best = ap.first; beste = &ap.second; }
+  }
+  *n_edges = k; *total_visits = tv; *root_value = rootn->V;
+  // MCTSGameAI::getValue MCTSGameAI.h:40-46
+  *best_q = (tv == 0 || !beste) ? rootn->V : beste->reward / beste->num_visits;
+  return k == 0 ? -1 : best;
+}
+
+// libstdc++ behaviours exposed for checking the HIP path's explicit emulations (tests only)
+void omcts_std_sort_desc(int n, const float* keys, uint16_t* order_out) {
+  std::vector<std::pair<Action, float>> v;
+  for (int i = 0; i < n; ++i) v.push_back(std::make_pair((Action)i, keys[i]));
+  using dt = std::pair<Action, float>;
+  std::sort(v.begin(), v.end(), [](const dt& a, const dt& b) { return a.second > b.second; });
+  for (int i = 0; i < n; ++i) order_out[i] = v[i].first;
+}
+void omcts_std_umap_order(int n, const uint16_t* keys_in_insert_order, uint16_t* iter_order_out) {
+  std::unordered_map<Action, int> m;
+  for (int i = 0; i < n; ++i) m.insert(std::make_pair(keys_in_insert_order[i], i));
+  int k = 0;
+  for (auto& p : m) iter_order_out[k++] = p.first;
+}
+
+}  // extern "C"

@@ -78,6 +78,19 @@ def oracle():
         L.go_playout.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]
         L.go_playout.restype = C.c_uint64
         L.go_sizeof_state.restype = C.c_int
+        # --- MCTS restatement (oracle/mcts.cpp)
+        _u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS")
+        L.omcts_create.argtypes = [_i32p, C.c_float, C.c_int, C.c_uint64]
+        L.omcts_create.restype = C.c_void_p
+        L.omcts_destroy.argtypes = [C.c_void_p]
+        L.omcts_clear.argtypes = [C.c_void_p]
+        L.omcts_advance.argtypes = [C.c_void_p, C.c_int]
+        L.omcts_stats.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
+        L.omcts_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _i32p, _u16p, _i32p, _f32p, _f32p, _i32p, _f32p, _f32p]
+        L.omcts_run.restype = C.c_int
+        L.omcts_scripted_policy.argtypes = [_u64p, C.c_uint64, _f32p, _f32p]
+        L.omcts_std_sort_desc.argtypes = [C.c_int, _f32p, _u16p]
+        L.omcts_std_umap_order.argtypes = [C.c_int, _u16p, _u16p]
         _oracle = L
     return _oracle
 
@@ -236,3 +249,42 @@ def go_grid_to_words(g, to_move=0, ply=0):
     w[19] = h
     w[20] = (to_move & 1) | (ply << 16) | (GO_NO_POINT << 32) | (GO_NO_POINT << 48)
     return w
+
+
+class OracleMcts:
+    """oracle/mcts.cpp: reference tree search restated (num_threads=1)."""
+
+    def __init__(self, num_rollouts=256, rollouts_per_batch=1, virtual_loss=1, use_prior=1, c_puct=1.5,
+                 unexplored_q_zero=0, root_unexplored_q_zero=0, persistent_tree=1, pick_method=0,
+                 policy_kind=0, policy_seed=0):
+        self.L = oracle()
+        iopt = np.array([num_rollouts, rollouts_per_batch, virtual_loss, use_prior, unexplored_q_zero,
+                         root_unexplored_q_zero, persistent_tree, pick_method], dtype=np.int32)
+        self.h = C.c_void_p(self.L.omcts_create(iopt, c_puct, policy_kind, policy_seed))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.omcts_destroy(self.h)
+            self.h = None
+
+    def run(self, game):
+        """game: AmGame. -> dict(best, edges=[(action, visits, reward, prior)], total_visits, root_value, best_q)"""
+        n = np.zeros(1, dtype=np.int32); tv = np.zeros(1, dtype=np.int32)
+        rv = np.zeros(1, dtype=np.float32); bq = np.zeros(1, dtype=np.float32)
+        acts = np.zeros(64, dtype=np.uint16); vis = np.zeros(64, dtype=np.int32)
+        rew = np.zeros(64, dtype=np.float32); pri = np.zeros(64, dtype=np.float32)
+        best = self.L.omcts_run(self.h, game.buf, 64, n, acts, vis, rew, pri, tv, rv, bq)
+        k = int(n[0])
+        return dict(best=best, edges=[(int(acts[i]), int(vis[i]), float(rew[i]), float(pri[i])) for i in range(k)],
+                    total_visits=int(tv[0]), root_value=float(rv[0]), best_q=float(bq[0]))
+
+    def advance(self, a):
+        self.L.omcts_advance(self.h, int(a))
+
+    def clear(self):
+        self.L.omcts_clear(self.h)
+
+    def stats(self):
+        o = np.zeros(4, dtype=np.int64)
+        self.L.omcts_stats(self.h, o)
+        return dict(rollouts=int(o[0]), evals=int(o[1]), depth_sum=int(o[2]), edge_sum=int(o[3]))
