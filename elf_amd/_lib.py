@@ -18,7 +18,7 @@ SYMBOLS = [
     "elfhip_boards_create", "elfhip_boards_destroy", "elfhip_boards_set_stream", "elfhip_boards_count",
     "elfhip_boards_game", "elfhip_boards_reset", "elfhip_boards_export", "elfhip_boards_import",
     "elfhip_boards_legal_mask", "elfhip_boards_step", "elfhip_boards_features", "elfhip_boards_evaluate",
-    "elfhip_boards_playout",
+    "elfhip_boards_playout", "elfhip_test_sort_order", "elfhip_test_umap_order",
 ]
 
 
@@ -59,6 +59,8 @@ def lib():
     L.elfhip_boards_features.argtypes = [vp, vp, i]
     L.elfhip_boards_evaluate.argtypes = [vp, vp]
     L.elfhip_boards_playout.argtypes = [vp, i, u64, u64, vp]
+    L.elfhip_test_sort_order.argtypes = [i, vp, vp]
+    L.elfhip_test_umap_order.argtypes = [i, vp, vp]
     _lib = L
     return L
 

@@ -4,6 +4,8 @@
 #include <cstring>
 #include <new>
 #include "common.h"
+#include "stdorder.h"
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -139,6 +141,24 @@ int elfhip_boards_playout(elfhip_boards* b, int nply, uint64_t seed, uint64_t fi
   if (nply < 0 || nply > (1 << 20)) { elfhip_set_error("boards_playout: nply=%d out of range", nply); return ELFHIP_EINVAL; }
   if (nply == 0) return ELFHIP_OK;
   return b->slab->playout(nply, seed, first_board_id, d_moves);
+}
+
+int elfhip_test_sort_order(int n, const float* h_keys, uint16_t* h_order) {
+  if (n < 0 || n > 65535 || !h_keys || !h_order) { elfhip_set_error("test_sort_order: bad arguments"); return ELFHIP_EINVAL; }
+  std::vector<stdorder::Item> v((size_t)n);
+  for (int i = 0; i < n; ++i) { v[i].key = h_keys[i]; v[i].idx = (uint16_t)i; }
+  stdorder::sort_desc(v.data(), n);
+  for (int i = 0; i < n; ++i) h_order[i] = v[i].idx;
+  return ELFHIP_OK;
+}
+
+int elfhip_test_umap_order(int m, const uint16_t* h_keys, uint16_t* h_iter_keys) {
+  if (m < 0 || m > 512 || !h_keys || !h_iter_keys) { elfhip_set_error("test_umap_order: bad arguments"); return ELFHIP_EINVAL; }
+  std::vector<int16_t> next((size_t)m + 1), buckets(544);
+  std::vector<uint16_t> pos((size_t)m + 1);
+  stdorder::umap_iteration_order(h_keys, m, next.data(), buckets.data(), pos.data());
+  for (int i = 0; i < m; ++i) h_iter_keys[i] = h_keys[pos[i]];
+  return ELFHIP_OK;
 }
 
 }  // extern "C"

@@ -107,6 +107,17 @@ int elfhip_boards_evaluate(elfhip_boards* b, float* d_value);
 int elfhip_boards_playout(elfhip_boards* b, int nply, uint64_t seed, uint64_t first_board_id,
                           unsigned long long* d_moves);
 
+/* ------------------------------------------------------------------------------------------------
+ * Host-only hooks for the explicit libstdc++-order emulations the search kernels use
+ * (elf_amd/csrc/stdorder.h).  No reference counterpart: they exist so CPU tests can compare the
+ * emulations with the real std::sort / std::unordered_map.
+ *   sort : order[i] = index of the i-th element after std::sort(desc by key) of n (idx,key) pairs
+ *   umap : iter_keys = keys in std::unordered_map<unsigned short,...> iteration order after
+ *          inserting the m distinct keys in the given order (m <= 512)
+ * ---------------------------------------------------------------------------------------------- */
+int elfhip_test_sort_order(int n, const float* h_keys, uint16_t* h_order);
+int elfhip_test_umap_order(int m, const uint16_t* h_keys, uint16_t* h_iter_keys);
+
 #ifdef __cplusplus
 }
 #endif
