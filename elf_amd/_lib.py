@@ -19,7 +19,18 @@ SYMBOLS = [
     "elfhip_boards_game", "elfhip_boards_reset", "elfhip_boards_export", "elfhip_boards_import",
     "elfhip_boards_legal_mask", "elfhip_boards_step", "elfhip_boards_features", "elfhip_boards_evaluate",
     "elfhip_boards_playout", "elfhip_test_sort_order", "elfhip_test_umap_order",
+    "elfhip_mcts_create", "elfhip_mcts_destroy", "elfhip_mcts_set_stream", "elfhip_mcts_clear", "elfhip_mcts_set_roots",
+    "elfhip_mcts_run_uniform", "elfhip_mcts_select", "elfhip_mcts_backup", "elfhip_mcts_result", "elfhip_mcts_advance",
+    "elfhip_mcts_stats",
 ]
+
+
+class TSOptions(C.Structure):
+    """elfhip_ts_options: TSOptions / SearchAlgoOptions of the reference (tree_search_options.h)."""
+    _fields_ = [("num_rollouts_per_thread", C.c_int), ("num_rollouts_per_batch", C.c_int), ("virtual_loss", C.c_int),
+                ("use_prior", C.c_int), ("c_puct", C.c_float), ("unexplored_q_zero", C.c_int),
+                ("root_unexplored_q_zero", C.c_int), ("persistent_tree", C.c_int), ("pick_method", C.c_int),
+                ("max_nodes", C.c_int), ("max_edges", C.c_int)]
 
 
 class GameInfo(C.Structure):
@@ -61,6 +72,17 @@ def lib():
     L.elfhip_boards_playout.argtypes = [vp, i, u64, u64, vp]
     L.elfhip_test_sort_order.argtypes = [i, vp, vp]
     L.elfhip_test_umap_order.argtypes = [i, vp, vp]
+    L.elfhip_mcts_create.argtypes = [i, i, C.POINTER(TSOptions), i, C.POINTER(vp)]
+    L.elfhip_mcts_destroy.argtypes = [vp]
+    L.elfhip_mcts_set_stream.argtypes = [vp, vp]
+    L.elfhip_mcts_clear.argtypes = [vp, vp]
+    L.elfhip_mcts_set_roots.argtypes = [vp, vp, vp]
+    L.elfhip_mcts_run_uniform.argtypes = [vp]
+    L.elfhip_mcts_select.argtypes = [vp, vp, vp, vp]
+    L.elfhip_mcts_backup.argtypes = [vp, vp, vp]
+    L.elfhip_mcts_result.argtypes = [vp] + [vp] * 9 + [i, vp]
+    L.elfhip_mcts_advance.argtypes = [vp, vp]
+    L.elfhip_mcts_stats.argtypes = [vp, vp, vp]
     _lib = L
     return L
 

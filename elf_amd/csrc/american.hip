@@ -189,17 +189,6 @@ am_features_kernel(const uint64_t* __restrict__ hist, const uint32_t* __restrict
   uint32_t m = hmeta[b];
   int len = m & 7, head = (m >> 3) & 7;
   uint32_t abits = (m >> 8) & 0x3F;
-  int y = lane >> 3, x = lane & 7;
-  // square -> padded bit index, black orientation (inverse of GameBoard.cc:230-232)
-  auto sq2bit = [](int yy, int xx) -> int {
-    int rr = 7 - yy;
-    int t = 6 + (rr & 1) - xx;
-    if (t < 0 || t > 6 || (t & 1)) return -1;
-    int buff = rr * 4 + (t >> 1);
-    return buff + (buff >> 3);
-  };
-  int bit_b = sq2bit(y, x);          // black's view
-  int bit_w = sq2bit(7 - y, 7 - x);  // white's view (180 degree rotation)
   for (int slot = 0; slot < 6; ++slot) {
     int k = slot - (6 - len);  // history index, oldest first; negative -> zero padding
     float pl[6] = {0, 0, 0, 0, 0, 0};
@@ -208,14 +197,7 @@ am_features_kernel(const uint64_t* __restrict__ hist, const uint32_t* __restrict
       uint64_t f0 = hist[(hs * 4 + 0) * (size_t)n + b], f1 = hist[(hs * 4 + 1) * (size_t)n + b];
       uint64_t k0 = hist[(hs * 4 + 2) * (size_t)n + b], k1 = hist[(hs * 4 + 3) * (size_t)n + b];
       int act = (abits >> hs) & 1;
-      // pawns / kings per colour (a king sits in both words; GetObservation tests kings first)
-      uint64_t pawn[2] = {f0 & ~k0, k1 & ~f1}, king[2] = {k0, f1};
-      int ba = act == 0 ? bit_b : bit_w;  // mover's planes in the mover's orientation
-      int bp = act == 0 ? bit_w : bit_b;  // opponent's planes in the opponent's orientation (Q7)
-      if (ba >= 0) { pl[0] = (pawn[act] >> ba) & 1; pl[1] = (king[act] >> ba) & 1; }
-      if (bp >= 0) { pl[2] = (pawn[act ^ 1] >> bp) & 1; pl[3] = (king[act ^ 1] >> bp) & 1; }
-      pl[4] = act == 0 ? 1.f : 0.f;
-      pl[5] = act == 1 ? 1.f : 0.f;
+      am_slot_planes(f0, f1, k0, k1, act, lane, pl);
     }
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
@@ -249,6 +231,7 @@ struct AmericanSlab : BoardSlab {
       elfhip_set_error("american: device allocation of %d boards failed", n);
       return ELFHIP_ENOMEM;
     }
+    dev_ptr[0] = w; dev_ptr[1] = hist; dev_ptr[2] = hmeta;
     return reset();
   }
   int reset() override {

@@ -203,4 +203,29 @@ __device__ inline void am_play(Am& s, int action, int t, int i) {
   s.w4 = (uint64_t)nactive | ((uint64_t)jumpflag << 1) | ((uint64_t)ply << 8) | ((uint64_t)action << 24) | repw;
 }
 
+// Feature planes of ONE history slot for the square owned by `lane` (lane = y*8+x).
+// BoardFeature::extract BoardFeature.cc:58-76 + GetObservation GameBoard.cc:210-277.
+// pl[0..3] = mover pawns / mover kings / opponent pawns / opponent kings, each in that player's
+// own orientation (Q7); pl[4], pl[5] = black / white to move.
+__device__ inline void am_slot_planes(uint64_t f0, uint64_t f1, uint64_t k0, uint64_t k1, int act, int lane, float pl[6]) {
+  const int y = lane >> 3, x = lane & 7;
+  // square -> padded bit index in black's orientation (inverse of GameBoard.cc:230-232)
+  auto sq2bit = [](int yy, int xx) -> int {
+    int rr = 7 - yy;
+    int t = 6 + (rr & 1) - xx;
+    if (t < 0 || t > 6 || (t & 1)) return -1;
+    int buff = rr * 4 + (t >> 1);
+    return buff + (buff >> 3);
+  };
+  const int bit_b = sq2bit(y, x), bit_w = sq2bit(7 - y, 7 - x);  // white's view = 180 degree rotation
+  // a king sits in both words of its colour; GetObservation tests kings first
+  uint64_t pawn[2] = {f0 & ~k0, k1 & ~f1}, king[2] = {k0, f1};
+  const int ba = act == 0 ? bit_b : bit_w, bp = act == 0 ? bit_w : bit_b;
+  pl[0] = pl[1] = pl[2] = pl[3] = 0.f;
+  if (ba >= 0) { pl[0] = (float)((pawn[act] >> ba) & 1); pl[1] = (float)((king[act] >> ba) & 1); }
+  if (bp >= 0) { pl[2] = (float)((pawn[act ^ 1] >> bp) & 1); pl[3] = (float)((king[act ^ 1] >> bp) & 1); }
+  pl[4] = act == 0 ? 1.f : 0.f;
+  pl[5] = act == 1 ? 1.f : 0.f;
+}
+
 }  // namespace amdev

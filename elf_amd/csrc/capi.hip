@@ -16,7 +16,6 @@ void elfhip_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-struct elfhip_boards { BoardSlab* slab; };
 
 extern "C" {
 

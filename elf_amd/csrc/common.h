@@ -39,6 +39,8 @@ struct BoardSlab {
   int game = 0, n = 0, device = 0;
   hipStream_t stream = nullptr;
   uint64_t step_counter = 0;  // plies driven by playout() since reset (RNG counter)
+  // raw device arrays other components read (american: [0]=words[6][n], [1]=hist[6][4][n], [2]=hmeta[n])
+  void* dev_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
   virtual ~BoardSlab() {}
   virtual int alloc() = 0;
   virtual int reset() = 0;
@@ -50,6 +52,8 @@ struct BoardSlab {
   virtual int evaluate(float* d_value) = 0;
   virtual int playout(int nply, uint64_t seed, uint64_t first_id, unsigned long long* d_moves) = 0;
 };
+
+struct elfhip_boards { BoardSlab* slab; };
 
 BoardSlab* elfhip_make_american();
 BoardSlab* elfhip_make_go19();

@@ -1,0 +1,102 @@
+"""Host-side mirror of the reference's MCTSAI_T / TreeSearchT interface (mcts.h:48-203,
+tree_search.h:405-622), batched over n trees that live in HBM.  Method names follow the reference:
+`run`, `treeAdvance`, `clear` (endGame/resetTree), plus the select/backup split used when the
+evaluator is an external network.  All computation is in libelfhip.so."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import TSOptions, check
+
+
+class TreeSearchBatch:
+    def __init__(self, game, n_trees, device=0, num_rollouts_per_thread=100, num_rollouts_per_batch=8, virtual_loss=0,
+                 use_prior=True, c_puct=5.0, unexplored_q_zero=False, root_unexplored_q_zero=False,
+                 persistent_tree=True, pick_method="most_visited", max_nodes=0, max_edges=0):
+        self.L = _lib.lib()
+        self.n = int(n_trees)
+        self.B = int(num_rollouts_per_batch)
+        self.R = int(num_rollouts_per_thread)
+        self.device = torch.device("cuda", device)
+        self.info = _lib.game_info(game)
+        pick = {"most_visited": 0, "strongest_prior": 1}[pick_method]
+        self.opt = TSOptions(self.R, self.B, int(virtual_loss), int(use_prior), float(c_puct), int(unexplored_q_zero),
+                             int(root_unexplored_q_zero), int(persistent_tree), pick, int(max_nodes), int(max_edges))
+        h = C.c_void_p()
+        check(self.L.elfhip_mcts_create(game, self.n, C.byref(self.opt), device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.elfhip_mcts_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream):
+        check(self.L.elfhip_mcts_set_stream(self.h, C.c_void_p(stream.cuda_stream if stream is not None else 0)))
+
+    def clear(self, which=None):
+        check(self.L.elfhip_mcts_clear(self.h, which.data_ptr() if which is not None else None))
+
+    def set_roots(self, boards):
+        ok = torch.empty(self.n, dtype=torch.uint8, device=self.device)
+        check(self.L.elfhip_mcts_set_roots(self.h, boards.h, ok.data_ptr()))
+        return ok
+
+    def run_uniform(self):
+        check(self.L.elfhip_mcts_run_uniform(self.h))
+
+    def select(self, want_states=True, want_features=False):
+        st = torch.empty((self.n, self.B, 6), dtype=torch.int64, device=self.device) if want_states else None
+        ft = torch.empty((self.n, self.B, self.info.num_planes, 8, 8), dtype=torch.float32, device=self.device) if want_features else None
+        ne = torch.empty((self.n, self.B), dtype=torch.uint8, device=self.device)
+        check(self.L.elfhip_mcts_select(self.h, st.data_ptr() if st is not None else None,
+                                        ft.data_ptr() if ft is not None else None, ne.data_ptr()))
+        return st, ft, ne
+
+    def backup(self, pi, value):
+        assert pi.dtype == torch.float32 and pi.is_contiguous() and pi.numel() == self.n * self.B * self.info.num_actions
+        assert value.dtype == torch.float32 and value.is_contiguous() and value.numel() == self.n * self.B
+        check(self.L.elfhip_mcts_backup(self.h, pi.data_ptr(), value.data_ptr()))
+
+    def run(self, evaluator):
+        """TreeSearchT::run with an external evaluator: evaluator(features[n*B,planes,8,8], states) -> (pi, V)"""
+        for _ in range((self.R + self.B - 1) // self.B):
+            st, ft, ne = self.select(want_states=True, want_features=True)
+            pi, v = evaluator(ft.view(self.n * self.B, self.info.num_planes, 8, 8), st, ne)
+            self.backup(pi.contiguous(), v.contiguous())
+
+    def result(self, edge_cap=64, with_policy=False):
+        dev, n = self.device, self.n
+        r = dict(best=torch.empty(n, dtype=torch.int16, device=dev), total_visits=torch.empty(n, dtype=torch.int32, device=dev),
+                 best_q=torch.empty(n, dtype=torch.float32, device=dev), root_value=torch.empty(n, dtype=torch.float32, device=dev),
+                 n_edges=torch.empty(n, dtype=torch.int32, device=dev),
+                 edge_action=torch.full((n, edge_cap), -1, dtype=torch.int16, device=dev),
+                 edge_visits=torch.zeros((n, edge_cap), dtype=torch.int32, device=dev),
+                 edge_reward=torch.zeros((n, edge_cap), dtype=torch.float32, device=dev),
+                 edge_prior=torch.zeros((n, edge_cap), dtype=torch.float32, device=dev))
+        pol = torch.empty((n, self.info.num_actions), dtype=torch.int32, device=dev) if with_policy else None
+        check(self.L.elfhip_mcts_result(self.h, r["best"].data_ptr(), r["total_visits"].data_ptr(), r["best_q"].data_ptr(),
+                                        r["root_value"].data_ptr(), r["n_edges"].data_ptr(), r["edge_action"].data_ptr(),
+                                        r["edge_visits"].data_ptr(), r["edge_reward"].data_ptr(), r["edge_prior"].data_ptr(),
+                                        edge_cap, pol.data_ptr() if with_policy else None))
+        if with_policy:
+            r["policy_visits"] = pol
+        return r
+
+    def treeAdvance(self, actions):
+        assert actions.dtype == torch.int16 and actions.is_cuda and actions.numel() == self.n
+        check(self.L.elfhip_mcts_advance(self.h, actions.data_ptr()))
+
+    def stats(self):
+        st = (C.c_ulonglong * 4)()
+        fl = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        check(self.L.elfhip_mcts_stats(self.h, st, fl.data_ptr()))
+        return dict(rollouts=st[0], evals=st[1], depth_sum=st[2], edge_sum=st[3]), fl

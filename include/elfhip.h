@@ -108,6 +108,66 @@ int elfhip_boards_playout(elfhip_boards* b, int nply, uint64_t seed, uint64_t fi
                           unsigned long long* d_moves);
 
 /* ------------------------------------------------------------------------------------------------
+ * Batched tree search: n_trees independent PUCT trees (one per game), one wavefront per tree.
+ * Replaces elf::ai::tree_search::TreeSearchT<S,A,Actor> + MCTSAI_T (tree_search.h:405-622,
+ * mcts.h:48-203) run with num_threads == 1, and the game actor MCTSGameActor (pre_evaluate /
+ * pi2response, MCTSGameActor.h:198-335).  Field names follow TSOptions / SearchAlgoOptions
+ * (tree_search_options.h:24-29,91-110); num_threads is fixed to 1 because bit-exact results are
+ * only defined there (hard part 3).  root_epsilon / root_alpha (Dirichlet-like root
+ * noise) are not built yet and must be 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int num_rollouts_per_thread; /* rollouts per run() */
+  int num_rollouts_per_batch;  /* 1..16 leaves selected before each evaluation */
+  int virtual_loss;
+  int use_prior;               /* alg_opt.use_prior */
+  float c_puct;                /* alg_opt.c_puct */
+  int unexplored_q_zero;       /* alg_opt.unexplored_q_zero */
+  int root_unexplored_q_zero;  /* alg_opt.root_unexplored_q_zero */
+  int persistent_tree;
+  int pick_method;             /* 0 "most_visited", 1 "strongest_prior" */
+  int max_nodes;               /* per tree per arena; 0 = 8*rollouts+64 */
+  int max_edges;               /* per tree per arena; 0 = 12*max_nodes */
+} elfhip_ts_options;
+
+typedef struct elfhip_mcts elfhip_mcts;
+
+int elfhip_mcts_create(int game, int n_trees, const elfhip_ts_options* opt, int device, elfhip_mcts** out);
+int elfhip_mcts_destroy(elfhip_mcts* m);
+int elfhip_mcts_set_stream(elfhip_mcts* m, void* hip_stream);
+/* MCTSAI_T::endGame -> resetTree (mcts.h:116-119,162-165).  d_which (nullable) [n_trees] u8 selects trees. */
+int elfhip_mcts_clear(elfhip_mcts* m, const uint8_t* d_which);
+/* TreeSearchT::setRootNodeState (tree_search.h:570-585) from board i of `b` for tree i (clears the
+ * tree first when persistent_tree == 0, mcts.h:167-173).  d_ok (nullable) [n_trees] u8: 0 where the
+ * stored root state differs from the board ("Root state is not the same"); such trees are parked. */
+int elfhip_mcts_set_roots(elfhip_mcts* m, elfhip_boards* b, uint8_t* d_ok);
+/* TreeSearchT::run with the uniform evaluator (pi = 1/num_actions before filtering, V = 0, terminal
+ * +-1): all ceil(rollouts/batch) batches inside ONE launch.  BASELINE.json configs[2]. */
+int elfhip_mcts_run_uniform(elfhip_mcts* m);
+/* One batch with an external evaluator (the network): select() descends num_rollouts_per_batch
+ * times per tree and emits, per slot [n_trees][batch]: d_leaf_states (nullable) 6 u64 board words,
+ * d_leaf_features (nullable) float [36][8][8] (BoardFeature::extract of the leaf, the "s" key),
+ * d_need_eval (nullable) u8 = 1 where (pi, V) of that slot will be consumed.  backup() then takes
+ * d_pi float [n_trees][batch][num_actions] (network probabilities, unfiltered) and d_value float
+ * [n_trees][batch], performs pi2response + setEvaluation on newly reached leaves and the batch's
+ * updateEdgeStats. */
+int elfhip_mcts_select(elfhip_mcts* m, uint64_t* d_leaf_states, float* d_leaf_features, uint8_t* d_need_eval);
+int elfhip_mcts_backup(elfhip_mcts* m, const float* d_pi, const float* d_value);
+/* chooseAction / MCTSResultT (tree_search_base.h:284-367) and MCTSGameAI::getValue (MCTSGameAI.h:40-46).
+ * All outputs nullable: d_best i16 [n] (-1: no edges), d_total_visits i32 [n], d_best_q f32 [n],
+ * d_root_value f32 [n], d_n_edges i32 [n], per-edge arrays [n][edge_cap] in the reference's edge
+ * iteration order, d_policy_visits i32 [n][num_actions] (visit count per action = mcts_policy). */
+int elfhip_mcts_result(elfhip_mcts* m, int16_t* d_best, int32_t* d_total_visits, float* d_best_q, float* d_root_value,
+                       int32_t* d_n_edges, int16_t* d_edge_action, int32_t* d_edge_visits, float* d_edge_reward,
+                       float* d_edge_prior, int edge_cap, int32_t* d_policy_visits);
+/* TreeSearchT::treeAdvance (tree_search_node.h:458-474) with d_actions i16 [n_trees] (negative = skip). */
+int elfhip_mcts_advance(elfhip_mcts* m, const int16_t* d_actions);
+/* Counters since creation: h_stats4 = {rollouts, network evaluations, sum of descent depths, edges
+ * created} (nullable); d_flags (nullable) i32 [n_trees]: non-zero = tree parked (1 node arena full,
+ * 2 edge arena full, 4 depth, 8 too many legal moves, 16 root mismatch).  Synchronises. */
+int elfhip_mcts_stats(elfhip_mcts* m, unsigned long long* h_stats4, int32_t* d_flags);
+
+/* ------------------------------------------------------------------------------------------------
  * Host-only hooks for the explicit libstdc++-order emulations the search kernels use
  * (elf_amd/csrc/stdorder.h).  No reference counterpart: they exist so CPU tests can compare the
  * emulations with the real std::sort / std::unordered_map.

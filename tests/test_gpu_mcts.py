@@ -1,0 +1,204 @@
+"""GPU parity of the batched tree search (through the C-ABI) against oracle/mcts.cpp, which is
+itself pinned to the compiled reference's known answers.  Visit counts, edge
+order, chosen actions, total visits: bit-exact.  Rewards / priors: bit-exact (parity configs use
+values whose float sums are exact, SURVEY 7 hard part 3)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import _oracle
+from tests._oracle import AmGame, OracleMcts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _edges(res, i):
+    k = int(res["n_edges"][i])
+    return [(int(res["edge_action"][i, j]), int(res["edge_visits"][i, j]), float(res["edge_reward"][i, j]),
+             float(res["edge_prior"][i, j])) for j in range(k)]
+
+
+def _cpu(res):
+    return {k: v.cpu().numpy() for k, v in res.items()}
+
+
+@pytest.mark.parametrize("batch", [1, 8])
+def test_appendix_c_known_answer_on_gpu(torch_cuda, golden_dir, batch):
+    """The compiled reference's own answers (uniform policy, 256 rollouts, vloss 1, c_puct 1.5)."""
+    torch = torch_cuda
+    from elf_amd.boards import BoardBatch, AMERICAN
+    from elf_amd.mcts import TreeSearchBatch
+    gold = json.load(open(os.path.join(golden_dir, "mcts_appendix_c.json")))["batch%d" % batch]
+    n = 4
+    bb = BoardBatch(AMERICAN, n)
+    ts = TreeSearchBatch(AMERICAN, n, num_rollouts_per_thread=256, num_rollouts_per_batch=batch, virtual_loss=1, c_puct=1.5)
+    actions, totals = [], []
+    for mv in range(12):
+        assert ts.set_roots(bb).cpu().numpy().all()
+        ts.run_uniform()
+        res = _cpu(ts.result())
+        for i in range(1, n):
+            assert _edges(res, i) == _edges(res, 0)
+        if mv < 3:
+            assert [[a, v] for (a, v, _, _) in _edges(res, 0)] == gold["move%d" % mv], mv
+        actions.append(int(res["best"][0])); totals.append(int(res["total_visits"][0]))
+        act = torch.tensor(res["best"], device="cuda")
+        assert bb.forward(act).cpu().numpy().all()
+        ts.treeAdvance(act)
+    assert actions == gold["first12_actions"] and totals == gold["total_visits"]
+    st, flags = ts.stats()
+    assert not flags.cpu().numpy().any()
+
+
+def _play_games(torch, n, nmoves, opts, policy_kind, seed, start_plies):
+    """Drive n GPU trees and n oracle searches side by side from different start positions."""
+    from elf_amd.boards import BoardBatch, AMERICAN
+    from elf_amd.mcts import TreeSearchBatch
+    L = _oracle.oracle()
+    rng = np.random.default_rng(seed)
+    games = [AmGame() for _ in range(n)]
+    bb = BoardBatch(AMERICAN, n)
+    # different openings per tree, played on both sides through forward()
+    for ply in range(start_plies):
+        acts = np.full(n, -1, dtype=np.int16)
+        for i, g in enumerate(games):
+            if ply >= i % (start_plies + 1) or g.terminated():
+                continue
+            m = np.zeros(3, dtype=np.uint64); L.am_legal_mask(g.board(), m)
+            legal = _oracle.mask_bits(m, 170)
+            acts[i] = legal[rng.integers(len(legal))]
+            assert g.forward(acts[i])
+        bb.forward(torch.tensor(acts, device="cuda"))
+    ts = TreeSearchBatch(AMERICAN, n, **opts)
+    oopts = dict(num_rollouts=opts["num_rollouts_per_thread"], rollouts_per_batch=opts["num_rollouts_per_batch"],
+                 virtual_loss=opts["virtual_loss"], c_puct=opts["c_puct"], use_prior=int(opts.get("use_prior", True)),
+                 unexplored_q_zero=int(opts.get("unexplored_q_zero", False)),
+                 root_unexplored_q_zero=int(opts.get("root_unexplored_q_zero", False)),
+                 persistent_tree=int(opts.get("persistent_tree", True)),
+                 pick_method={"most_visited": 0, "strongest_prior": 1}[opts.get("pick_method", "most_visited")])
+    oracles = [OracleMcts(policy_kind=policy_kind, policy_seed=seed, **oopts) for _ in range(n)]
+    B = opts["num_rollouts_per_batch"]
+
+    def evaluator(feat, states, need):
+        s = states.cpu().numpy().view(np.uint64).reshape(n * B, 6)
+        pi = np.zeros((n * B, 170), dtype=np.float32); v = np.zeros(n * B, dtype=np.float32)
+        vv = np.zeros(1, dtype=np.float32)
+        for k in range(n * B):
+            L.omcts_scripted_policy(np.ascontiguousarray(s[k]), seed, pi[k], vv)
+            v[k] = vv[0]
+        return torch.tensor(pi, device="cuda"), torch.tensor(v, device="cuda")
+
+    for mv in range(nmoves):
+        assert ts.set_roots(bb).cpu().numpy().all()
+        if policy_kind == 0:
+            ts.run_uniform()
+        else:
+            ts.run(evaluator)
+        res = _cpu(ts.result(with_policy=True))
+        acts = np.full(n, -1, dtype=np.int16)
+        for i, (g, o) in enumerate(zip(games, oracles)):
+            r = o.run(g)
+            assert _edges(res, i) == r["edges"], (mv, i)
+            assert int(res["total_visits"][i]) == r["total_visits"] and float(res["root_value"][i]) == r["root_value"]
+            pol = np.zeros(170, dtype=np.int32)
+            for (a, vis, _, _) in r["edges"]:
+                pol[a] = vis
+            assert np.array_equal(res["policy_visits"][i], pol)
+            if r["edges"]:
+                assert int(res["best"][i]) == r["best"], (mv, i)
+                assert float(res["best_q"][i]) == r["best_q"] or (np.isnan(res["best_q"][i]) and np.isnan(r["best_q"]))
+                acts[i] = r["best"]
+                assert g.forward(r["best"])
+                o.advance(r["best"])
+            else:
+                assert int(res["best"][i]) == -1
+        act = torch.tensor(acts, device="cuda")
+        bb.forward(act)
+        ts.treeAdvance(act)
+    st, flags = ts.stats()
+    assert not flags.cpu().numpy().any()
+    tot = {k: sum(o.stats()[k] for o in oracles) for k in ("rollouts", "evals", "depth_sum", "edge_sum")}
+    assert st == tot, (st, tot)
+
+
+def test_uniform_policy_many_positions(torch_cuda):
+    _play_games(torch_cuda, 48, 10, dict(num_rollouts_per_thread=96, num_rollouts_per_batch=4, virtual_loss=1, c_puct=1.5),
+                policy_kind=0, seed=3, start_plies=30)
+
+
+def test_scripted_network_split_path_batch1(torch_cuda):
+    _play_games(torch_cuda, 12, 8, dict(num_rollouts_per_thread=64, num_rollouts_per_batch=1, virtual_loss=3, c_puct=0.9),
+                policy_kind=1, seed=11, start_plies=10)
+
+
+def test_scripted_network_split_path_batch8_and_options(torch_cuda):
+    _play_games(torch_cuda, 12, 6, dict(num_rollouts_per_thread=64, num_rollouts_per_batch=8, virtual_loss=1, c_puct=1.5,
+                                        root_unexplored_q_zero=True),
+                policy_kind=1, seed=5, start_plies=12)
+    _play_games(torch_cuda, 8, 5, dict(num_rollouts_per_thread=40, num_rollouts_per_batch=5, virtual_loss=0, c_puct=2.0,
+                                       unexplored_q_zero=True, persistent_tree=False, pick_method="strongest_prior"),
+                policy_kind=1, seed=6, start_plies=6)
+
+
+def test_late_game_terminal_nodes(torch_cuda):
+    """Start deep in the game so searches reach terminal positions (value +-1, no edges)."""
+    _play_games(torch_cuda, 24, 14, dict(num_rollouts_per_thread=64, num_rollouts_per_batch=2, virtual_loss=1, c_puct=1.5),
+                policy_kind=0, seed=9, start_plies=70)
+
+
+def test_leaf_features_match_game_history(torch_cuda):
+    """select()'s feature planes for a leaf == BoardFeature planes of the game after the same moves."""
+    torch = torch_cuda
+    from elf_amd.boards import BoardBatch, AMERICAN
+    from elf_amd.mcts import TreeSearchBatch
+    L = _oracle.oracle()
+    n = 6
+    games = [AmGame() for _ in range(n)]
+    bb = BoardBatch(AMERICAN, n)
+    rng = np.random.default_rng(4)
+    for ply in range(9):
+        acts = np.full(n, -1, dtype=np.int16)
+        for i, g in enumerate(games):
+            if ply > i + 2:
+                continue
+            m = np.zeros(3, dtype=np.uint64); L.am_legal_mask(g.board(), m)
+            legal = _oracle.mask_bits(m, 170)
+            acts[i] = legal[rng.integers(len(legal))]
+            g.forward(acts[i])
+        bb.forward(torch.tensor(acts, device="cuda"))
+    ts = TreeSearchBatch(AMERICAN, n, num_rollouts_per_thread=5, num_rollouts_per_batch=1, virtual_loss=1, c_puct=1.5)
+    ts.set_roots(bb)
+    ts.run_uniform()   # builds a small tree
+    st, ft, ne = ts.select(want_states=True, want_features=True)
+    st = st.cpu().numpy().view(np.uint64).reshape(n, 6); ft = ft.cpu().numpy().reshape(n, 36, 8, 8)
+    # find the path to each leaf by brute force over short move sequences from the root game
+    import copy
+    for i, g in enumerate(games):
+        found = False
+        frontier = [(copy.deepcopy(g.buf.raw), [])]
+        for depth in range(4):
+            nxt = []
+            for raw, path in frontier:
+                gg = AmGame(); gg.buf.raw = raw
+                if np.array_equal(gg.board(), st[i]):
+                    assert np.array_equal(gg.features(), ft[i]), i
+                    found = True
+                    break
+                m = np.zeros(3, dtype=np.uint64); L.am_legal_mask(gg.board(), m)
+                for a in _oracle.mask_bits(m, 170):
+                    g2 = AmGame(); g2.buf.raw = raw
+                    g2.forward(a)
+                    nxt.append((g2.buf.raw, path + [a]))
+            if found:
+                break
+            frontier = nxt
+        assert found, i
