@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Secondary benchmark: policy/value forward, OpenGo shape (18 planes, 19x19, 20 blocks x 224,
+362 actions; BASELINE.json configs[3]) and checkers shape (36, 8x8, 10 x 128, 170), seeded random
+weights, bf16 MFMA.  Reports positions/s and achieved TFLOP/s against the 2.5 PFLOP/s dense bf16 peak."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def macs(C, H, dim, blocks, A):
+    hw = H * H
+    return hw * (9 * C * dim + blocks * 2 * 9 * dim * dim + 2 * dim) + hw * A + hw * 256 + 256
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="go", choices=["go", "checkers"])
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=10)
+    a = ap.parse_args()
+    import torch
+    from elf_amd.net import PolicyValueNet
+    from oracle.model_ref import seeded_model
+    cfg = dict(planes=18, board=19, dim=224, num_block=20, num_action=362) if a.shape == "go" else \
+        dict(planes=36, board=8, dim=128, num_block=10, num_action=170)
+    net = PolicyValueNet(max_batch=a.batch, **cfg)
+    net.load_state_dict(seeded_model(seed=0, **cfg).state_dict())
+    x = (torch.rand((a.batch, cfg["planes"], cfg["board"], cfg["board"]), device="cuda") < 0.3).float()
+    for _ in range(2):
+        net.forward(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        net.forward(x)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1) / a.steps
+    fl = 2 * macs(cfg["planes"], cfg["board"], cfg["dim"], cfg["num_block"], cfg["num_action"])
+    tf = fl * a.batch / (ms * 1e-3) / 1e12
+    print(json.dumps({"metric": "net_positions_per_sec", "value": a.batch * a.steps / dt, "unit": "positions/s",
+                      "config": {"workload": "%s-shape policy/value forward, batch %d, bf16 MFMA" % (a.shape, a.batch), **cfg},
+                      "ms_per_forward": ms, "gflop_per_position": fl / 1e9,
+                      "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
+                                   "traffic": None, "kernel": "conv3x3_kernel<%d>" % cfg["dim"]}}))
+
+
+if __name__ == "__main__":
+    main()

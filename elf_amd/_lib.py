@@ -22,7 +22,14 @@ SYMBOLS = [
     "elfhip_mcts_create", "elfhip_mcts_destroy", "elfhip_mcts_set_stream", "elfhip_mcts_clear", "elfhip_mcts_set_roots",
     "elfhip_mcts_run_uniform", "elfhip_mcts_select", "elfhip_mcts_backup", "elfhip_mcts_result", "elfhip_mcts_advance",
     "elfhip_mcts_stats",
+    "elfhip_net_create", "elfhip_net_destroy", "elfhip_net_set_stream", "elfhip_net_param_count", "elfhip_net_load",
+    "elfhip_net_forward",
 ]
+
+
+class NetConfig(C.Structure):
+    _fields_ = [("planes", C.c_int), ("board", C.c_int), ("dim", C.c_int), ("num_block", C.c_int),
+                ("num_action", C.c_int), ("bn_eps", C.c_float)]
 
 
 class TSOptions(C.Structure):
@@ -83,6 +90,13 @@ def lib():
     L.elfhip_mcts_result.argtypes = [vp] + [vp] * 9 + [i, vp]
     L.elfhip_mcts_advance.argtypes = [vp, vp]
     L.elfhip_mcts_stats.argtypes = [vp, vp, vp]
+    L.elfhip_net_create.argtypes = [C.POINTER(NetConfig), i, i, C.POINTER(vp)]
+    L.elfhip_net_destroy.argtypes = [vp]
+    L.elfhip_net_set_stream.argtypes = [vp, vp]
+    L.elfhip_net_param_count.argtypes = [C.POINTER(NetConfig)]
+    L.elfhip_net_param_count.restype = C.c_longlong
+    L.elfhip_net_load.argtypes = [vp, vp, C.c_longlong]
+    L.elfhip_net_forward.argtypes = [vp, vp, i, vp, vp, vp]
     _lib = L
     return L
 

@@ -1,0 +1,405 @@
+// ResNet policy/value forward on gfx950 (bf16 MFMA, fp32 accumulate) - the one dense contraction
+// of the self-play path.  Replaces Model_PolicyValue.forward of the reference
+// (src_py/elfgames/american_checkers/model_american_checkers.py:325-349; Block :21-90; heads
+// :207-229), evaluated in eval mode: BatchNorm uses running statistics and is folded into the
+// preceding convolution when the weights are loaded.
+//
+// Layout: activations are bf16, NHWC, spatially zero-padded ([B][H+2][W+2][C]) so the 3x3 taps
+// need no boundary tests.  A 3x3 convolution is an implicit GEMM  D[co][pos] = sum_{tap,ci}
+// W[tap][co][ci] * X[pos + tap][ci]:  weights are the MFMA A operand (rows = output channels),
+// activations the B operand (columns = positions), so each lane ends up with 4 consecutive output
+// channels of one position = one 8-byte NHWC store.  Tile: 128 positions x all output channels per
+// 256-thread workgroup (4 waves x 32 positions), K stepped 32 input channels at a time through
+// LDS (rows padded to 80 B: conflict-free ds_read_b128), v_mfma_f32_16x16x32_bf16.
+// Bias (+ residual) + ReLU are fused in the epilogue.  Heads run in fp32.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ inline uint16_t f2bf(float f) {  // round to nearest even (inputs are finite)
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ inline float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+constexpr int KC = 32;        // input channels per K step
+constexpr int LROW = 40;      // LDS row stride in bf16 (32 data + 8 pad = 80 B)
+constexpr int BP = 128;       // positions per workgroup
+
+// "s" [B][C][H][W] f32  ->  padded NHWC bf16 [B][H+2][W+2][CP] (interior only; borders pre-zeroed)
+__global__ void net_pack_input_kernel(const float* __restrict__ s, uint16_t* __restrict__ x, int B, int C, int H, int W, int CP) {
+  const size_t total = (size_t)B * H * W * CP;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % CP); size_t p = i / CP;
+    int xw = (int)(p % W); p /= W;
+    int y = (int)(p % H); int n = (int)(p / H);
+    float v = c < C ? s[(((size_t)n * C + c) * H + y) * W + xw] : 0.f;
+    x[(((size_t)n * (H + 2) + y + 1) * (W + 2) + xw + 1) * CP + c] = f2bf(v);
+  }
+}
+
+// 3x3 same-padding convolution + bias (+ residual) + ReLU.  CIN, COUT multiples of 32 / 16.
+//   x   [B][H+2][W+2][CIN]  bf16 (padded)        w [9][COUT][CIN] bf16        bias [COUT] f32
+//   res nullable, same layout as out             out [B][H+2][W+2][COUT] bf16 (interior written)
+template <int COUT>
+__global__ void __launch_bounds__(256)
+conv3x3_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
+               const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int B, int H, int W, int CIN, int relu) {
+  constexpr int MT = COUT / 16;  // output-channel tiles
+  __shared__ __attribute__((aligned(16))) uint16_t sW[COUT * LROW];
+  __shared__ __attribute__((aligned(16))) uint16_t sX[BP * LROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = B * H * W;
+  const int m0 = blockIdx.x * BP;
+  const int PW = W + 2;
+  // the two activation rows this thread stages: row = tid/2 (+0), 32 B halves  -> 128 rows x 64 B
+  const int srow = tid >> 1, shalf = tid & 1;
+  size_t sbase;
+  {
+    int m = min(m0 + srow, M - 1);
+    int xw = m % W, t = m / W, y = t % H, n = t / H;
+    sbase = (((size_t)n * (H + 2) + y + 1) * PW + xw + 1) * CIN;
+  }
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
+
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const long toff = ((long)dy * PW + dx) * CIN;
+    for (int c0 = 0; c0 < CIN; c0 += KC) {
+      __syncthreads();
+      {  // activations: 128 rows x 32 ch; each thread 16 channels (32 B)
+        const uint4* g = (const uint4*)(x + (long)sbase + toff + c0 + shalf * 16);
+        uint4 v0 = g[0], v1 = g[1];
+        uint4* d = (uint4*)(sX + srow * LROW + shalf * 16);
+        d[0] = v0; d[1] = v1;
+      }
+      // weights: COUT rows x 32 ch = COUT*4 chunks of 16 B
+      for (int i = tid; i < COUT * 4; i += 256) {
+        const int co = i >> 2, q = i & 3;
+        const uint4 v = *(const uint4*)(w + ((size_t)tap * COUT + co) * CIN + c0 + q * 8);
+        *(uint4*)(sW + co * LROW + q * 8) = v;
+      }
+      __syncthreads();
+      const int kq = (lane >> 4) * 8, r16 = lane & 15;
+      bf16x8 b0 = *(const bf16x8*)(sX + (wave * 32 + r16) * LROW + kq);
+      bf16x8 b1 = *(const bf16x8*)(sX + (wave * 32 + 16 + r16) * LROW + kq);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        bf16x8 a = *(const bf16x8*)(sW + (mt * 16 + r16) * LROW + kq);
+        acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[mt][0], 0, 0, 0);
+        acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[mt][1], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: lane holds position (lane&15) of each of its 2 position tiles, channels 4*(lane>>4)+reg of each co tile
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int m = m0 + wave * 32 + nt * 16 + (lane & 15);
+    if (m >= M) continue;
+    int xw = m % W, t = m / W, y = t % H, n = t / H;
+    const size_t obase = (((size_t)n * (H + 2) + y + 1) * PW + xw + 1) * COUT;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co = mt * 16 + (lane >> 4) * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] + bias[co + r];
+      if (res) {
+        const uint2 rr = *(const uint2*)(res + obase + co);
+        v[0] += bf2f((uint16_t)(rr.x & 0xFFFF)); v[1] += bf2f((uint16_t)(rr.x >> 16));
+        v[2] += bf2f((uint16_t)(rr.y & 0xFFFF)); v[3] += bf2f((uint16_t)(rr.y >> 16));
+      }
+      if (relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      uint2 o;
+      o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+      o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      *(uint2*)(out + obase + co) = o;
+    }
+  }
+}
+
+// Heads (model_american_checkers.py:339-347), fp32.  One workgroup per board.
+//   pi  = exp(logsoftmax(pi_linear(relu(bn(conv1x1_pi(s))))))     V = tanh(lin2(relu(lin1(relu(bn(conv1x1_v(s)))))))
+__global__ void __launch_bounds__(256)
+net_heads_kernel(const uint16_t* __restrict__ x, int H, int W, int C, int A,
+                 const float* __restrict__ wpi, float bpi, const float* __restrict__ wv, float bv,
+                 const float* __restrict__ pl_w, const float* __restrict__ pl_b,
+                 const float* __restrict__ v1_w, const float* __restrict__ v1_b,
+                 const float* __restrict__ v2_w, float v2_b,
+                 float* __restrict__ pi_out, float* __restrict__ logpi_out, float* __restrict__ v_out) {
+  extern __shared__ float sm[];
+  const int HW = H * W;
+  float* fpi = sm;            // [HW]
+  float* fv = sm + HW;        // [HW]
+  float* logits = fv + HW;    // [A]
+  float* hid = logits + A;    // [256]
+  __shared__ float red[8];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int p = tid; p < HW; p += 256) {
+    const int y = p / W, xw = p % W;
+    const uint16_t* row = x + (((size_t)n * (H + 2) + y + 1) * (W + 2) + xw + 1) * C;
+    float a = 0.f, b = 0.f;
+    for (int c = 0; c < C; c += 8) {
+      const uint4 v = *(const uint4*)(row + c);
+      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float lo = bf2f((uint16_t)(u[q] & 0xFFFF)), hi = bf2f((uint16_t)(u[q] >> 16));
+        a += lo * wpi[c + 2 * q] + hi * wpi[c + 2 * q + 1];
+        b += lo * wv[c + 2 * q] + hi * wv[c + 2 * q + 1];
+      }
+    }
+    fpi[p] = fmaxf(a + bpi, 0.f);
+    fv[p] = fmaxf(b + bv, 0.f);
+  }
+  __syncthreads();
+  for (int a = tid; a < A; a += 256) {
+    float acc = pl_b[a];
+    const float* wr = pl_w + (size_t)a * HW;
+    for (int p = 0; p < HW; ++p) acc += wr[p] * fpi[p];
+    logits[a] = acc;
+  }
+  {
+    float acc = v1_b[tid];
+    const float* wr = v1_w + (size_t)tid * HW;
+    for (int p = 0; p < HW; ++p) acc += wr[p] * fv[p];
+    hid[tid] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  // log-softmax over A
+  float mx = -INFINITY;
+  for (int a = tid; a < A; a += 256) mx = fmaxf(mx, logits[a]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float se = 0.f;
+  for (int a = tid; a < A; a += 256) se += expf(logits[a] - mx);
+  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = se;
+  __syncthreads();
+  const float lse = mx + logf(red[4] + red[5] + red[6] + red[7]);
+  for (int a = tid; a < A; a += 256) {
+    const float lp = logits[a] - lse;
+    if (logpi_out) logpi_out[(size_t)n * A + a] = lp;
+    pi_out[(size_t)n * A + a] = expf(lp);
+  }
+  // value
+  float pv = hid[tid] * v2_w[tid];
+  for (int o = 32; o > 0; o >>= 1) pv += __shfl_xor(pv, o);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = pv;
+  __syncthreads();
+  if (tid == 0) v_out[n] = tanhf(red[0] + red[1] + red[2] + red[3] + v2_b);
+}
+
+#define NALLOC(ptr, bytes)                                                                       \
+  do {                                                                                           \
+    if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) {                                      \
+      elfhip_set_error("net: device allocation of %zu bytes failed", (size_t)(bytes));            \
+      return ELFHIP_ENOMEM;                                                                      \
+    }                                                                                            \
+    allocs.push_back((void*)(ptr));                                                              \
+  } while (0)
+
+struct ConvW { uint16_t* w = nullptr; float* b = nullptr; int cin = 0; };
+
+struct NetImpl {
+  elfhip_net_config cfg{};
+  int device = 0, max_batch = 0, cin_pad = 0;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  std::vector<ConvW> convs;  // stem + 2 per block
+  float *wpi = nullptr, *wv = nullptr, *pl_w = nullptr, *pl_b = nullptr, *v1_w = nullptr, *v1_b = nullptr, *v2_w = nullptr;
+  float bpi = 0, bv = 0, v2_b = 0;
+  uint16_t *xin = nullptr, *act[3] = {nullptr, nullptr, nullptr};
+  bool loaded = false;
+  ~NetImpl() { for (void* p : allocs) (void)hipFree(p); }
+
+  size_t param_count() const {
+    const size_t d = cfg.dim, hw = (size_t)cfg.board * cfg.board;
+    size_t n = d * cfg.planes * 9 + d + 4 * d;
+    n += (size_t)cfg.num_block * 2 * (d * d * 9 + d + 4 * d);
+    n += 2 * (d + 1 + 4);
+    n += (size_t)cfg.num_action * hw + cfg.num_action + 256 * hw + 256 + 256 + 1;
+    return n;
+  }
+
+  int alloc() {
+    const int d = cfg.dim, H = cfg.board;
+    cin_pad = (cfg.planes + KC - 1) / KC * KC;
+    const size_t pos = (size_t)max_batch * (H + 2) * (H + 2);
+    NALLOC(xin, pos * cin_pad * 2);
+    for (int i = 0; i < 3; ++i) NALLOC(act[i], pos * d * 2);
+    HIPCHECK(hipMemsetAsync(xin, 0, pos * cin_pad * 2, stream));
+    for (int i = 0; i < 3; ++i) HIPCHECK(hipMemsetAsync(act[i], 0, pos * d * 2, stream));
+    convs.resize(1 + 2 * cfg.num_block);
+    for (size_t i = 0; i < convs.size(); ++i) {
+      convs[i].cin = i == 0 ? cin_pad : d;
+      NALLOC(convs[i].w, (size_t)9 * d * convs[i].cin * 2);
+      NALLOC(convs[i].b, (size_t)d * 4);
+    }
+    const size_t hw = (size_t)H * H;
+    NALLOC(wpi, d * 4); NALLOC(wv, d * 4);
+    NALLOC(pl_w, cfg.num_action * hw * 4); NALLOC(pl_b, cfg.num_action * 4);
+    NALLOC(v1_w, 256 * hw * 4); NALLOC(v1_b, 256 * 4); NALLOC(v2_w, 256 * 4);
+    return ELFHIP_OK;
+  }
+
+  // h = flat fp32 parameters in the reference's state_dict order (see elfhip.h); folds BN, casts to bf16
+  int load(const float* h, size_t n) {
+    if (n != param_count()) { elfhip_set_error("net_load: expected %zu floats, got %zu", param_count(), n); return ELFHIP_EINVAL; }
+    const int d = cfg.dim, H = cfg.board;
+    const size_t hw = (size_t)H * H;
+    auto bf = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+    const float* p = h;
+    for (size_t li = 0; li < convs.size(); ++li) {
+      const int cin = li == 0 ? cfg.planes : d, cp = convs[li].cin;
+      const float* wt = p; p += (size_t)d * cin * 9;
+      const float* cb = p; p += d;
+      const float *g = p, *be = p + d, *mu = p + 2 * d, *var = p + 3 * d; p += 4 * d;
+      std::vector<uint16_t> wq((size_t)9 * d * cp, 0);
+      std::vector<float> bq(d);
+      for (int co = 0; co < d; ++co) {
+        const float sc = g[co] / std::sqrt(var[co] + cfg.bn_eps);
+        bq[co] = (cb[co] - mu[co]) * sc + be[co];
+        for (int ci = 0; ci < cin; ++ci)
+          for (int t = 0; t < 9; ++t) wq[((size_t)t * d + co) * cp + ci] = bf(wt[((size_t)co * cin + ci) * 9 + t] * sc);
+      }
+      HIPCHECK(hipMemcpy(convs[li].w, wq.data(), wq.size() * 2, hipMemcpyHostToDevice));
+      HIPCHECK(hipMemcpy(convs[li].b, bq.data(), bq.size() * 4, hipMemcpyHostToDevice));
+    }
+    auto head1x1 = [&](float* dw, float& db) -> int {
+      const float* wt = p; p += d;
+      const float cb = *p++; const float g = p[0], be = p[1], mu = p[2], var = p[3]; p += 4;
+      const float sc = g / std::sqrt(var + cfg.bn_eps);
+      std::vector<float> wf(d);
+      for (int c = 0; c < d; ++c) wf[c] = wt[c] * sc;
+      db = (cb - mu) * sc + be;
+      HIPCHECK(hipMemcpy(dw, wf.data(), (size_t)d * 4, hipMemcpyHostToDevice));
+      return ELFHIP_OK;
+    };
+    int rc = head1x1(wpi, bpi); if (rc) return rc;
+    rc = head1x1(wv, bv); if (rc) return rc;
+    HIPCHECK(hipMemcpy(pl_w, p, cfg.num_action * hw * 4, hipMemcpyHostToDevice)); p += cfg.num_action * hw;
+    HIPCHECK(hipMemcpy(pl_b, p, cfg.num_action * 4, hipMemcpyHostToDevice)); p += cfg.num_action;
+    HIPCHECK(hipMemcpy(v1_w, p, 256 * hw * 4, hipMemcpyHostToDevice)); p += 256 * hw;
+    HIPCHECK(hipMemcpy(v1_b, p, 256 * 4, hipMemcpyHostToDevice)); p += 256;
+    HIPCHECK(hipMemcpy(v2_w, p, 256 * 4, hipMemcpyHostToDevice)); p += 256;
+    v2_b = *p++;
+    loaded = true;
+    return ELFHIP_OK;
+  }
+
+  template <int COUT>
+  void launch_conv(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
+    const int M = B * cfg.board * cfg.board;
+    hipLaunchKernelGGL(conv3x3_kernel<COUT>, dim3((M + BP - 1) / BP), dim3(256), 0, stream, x, c.w, c.b, res, out, B,
+                       cfg.board, cfg.board, c.cin, relu);
+  }
+  void conv(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
+    switch (cfg.dim) {
+      case 32: launch_conv<32>(x, c, res, out, B, relu); break;
+      case 64: launch_conv<64>(x, c, res, out, B, relu); break;
+      case 128: launch_conv<128>(x, c, res, out, B, relu); break;
+      case 224: launch_conv<224>(x, c, res, out, B, relu); break;
+      default: launch_conv<256>(x, c, res, out, B, relu); break;
+    }
+  }
+
+  int forward(const float* d_s, int B, float* d_pi, float* d_logpi, float* d_v) {
+    const int H = cfg.board;
+    hipLaunchKernelGGL(net_pack_input_kernel, dim3(std::min<size_t>(4096, ((size_t)B * H * H * cin_pad + 255) / 256)), dim3(256),
+                       0, stream, d_s, xin, B, cfg.planes, H, H, cin_pad);
+    conv(xin, convs[0], nullptr, act[0], B, 1);                 // init_conv: conv + BN + ReLU
+    int cur = 0;
+    for (int k = 0; k < cfg.num_block; ++k) {                   // Block.forward :85-90
+      const int t1 = (cur + 1) % 3, t2 = (cur + 2) % 3;
+      conv(act[cur], convs[1 + 2 * k], nullptr, act[t1], B, 1); // conv_lower: conv + BN + ReLU
+      conv(act[t1], convs[2 + 2 * k], act[cur], act[t2], B, 1); // conv_upper: conv + BN, + s, ReLU
+      cur = t2;
+    }
+    const size_t sm = ((size_t)2 * H * H + cfg.num_action + 256) * 4;
+    hipLaunchKernelGGL(net_heads_kernel, dim3(B), dim3(256), sm, stream, act[cur], H, H, cfg.dim, cfg.num_action, wpi, bpi, wv,
+                       bv, pl_w, pl_b, v1_w, v1_b, v2_w, v2_b, d_pi, d_logpi, d_v);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+};
+
+}  // namespace
+
+struct elfhip_net { NetImpl* n; };
+
+#define CHECK_N(h)                                                                                   \
+  if (!(h) || !(h)->n) { elfhip_set_error("%s: null handle", __func__); return ELFHIP_EINVAL; }        \
+  HIPCHECK(hipSetDevice((h)->n->device));
+
+extern "C" {
+
+int elfhip_net_create(const elfhip_net_config* cfg, int max_batch, int device, elfhip_net** out) {
+  if (!cfg || !out) { elfhip_set_error("net_create: null argument"); return ELFHIP_EINVAL; }
+  *out = nullptr;
+  const bool dim_ok = cfg->dim == 32 || cfg->dim == 64 || cfg->dim == 128 || cfg->dim == 224 || cfg->dim == 256;
+  if (!dim_ok || cfg->planes < 1 || cfg->planes > 64 || cfg->board < 3 || cfg->board > 19 || cfg->num_block < 0 ||
+      cfg->num_block > 64 || cfg->num_action < 1 || cfg->num_action > 1024 || max_batch < 1 || max_batch > (1 << 20)) {
+    elfhip_set_error("net_create: unsupported config (dim must be 32/64/128/224/256, board 3..19, planes <= 64)");
+    return ELFHIP_EINVAL;
+  }
+  int ndev = elfhip_device_count();
+  if (ndev < 0) return ndev;
+  if (device < 0 || device >= ndev) { elfhip_set_error("net_create: device %d not in [0,%d)", device, ndev); return ELFHIP_EINVAL; }
+  HIPCHECK(hipSetDevice(device));
+  NetImpl* n = new (std::nothrow) NetImpl();
+  if (!n) { elfhip_set_error("net_create: host allocation failed"); return ELFHIP_ENOMEM; }
+  n->cfg = *cfg; n->device = device; n->max_batch = max_batch;
+  int rc = n->alloc();
+  if (rc != ELFHIP_OK) { delete n; return rc; }
+  *out = new elfhip_net{n};
+  return ELFHIP_OK;
+}
+
+int elfhip_net_destroy(elfhip_net* h) {
+  if (!h) return ELFHIP_OK;
+  if (h->n) { (void)hipSetDevice(h->n->device); (void)hipStreamSynchronize(h->n->stream); delete h->n; }
+  delete h;
+  return ELFHIP_OK;
+}
+
+int elfhip_net_set_stream(elfhip_net* h, void* s) { CHECK_N(h); h->n->stream = (hipStream_t)s; return ELFHIP_OK; }
+
+long long elfhip_net_param_count(const elfhip_net_config* cfg) {
+  if (!cfg) return ELFHIP_EINVAL;
+  NetImpl t; t.cfg = *cfg;
+  return (long long)t.param_count();
+}
+
+int elfhip_net_load(elfhip_net* h, const float* h_params, long long n_params) {
+  CHECK_N(h);
+  if (!h_params) { elfhip_set_error("net_load: null params"); return ELFHIP_EINVAL; }
+  return h->n->load(h_params, (size_t)n_params);
+}
+
+int elfhip_net_forward(elfhip_net* h, const float* d_s, int batch, float* d_pi, float* d_logpi, float* d_v) {
+  CHECK_N(h);
+  if (!h->n->loaded) { elfhip_set_error("net_forward: no weights loaded"); return ELFHIP_ESTATE; }
+  if (!d_s || !d_pi || !d_v) { elfhip_set_error("net_forward: null buffer"); return ELFHIP_EINVAL; }
+  if (batch < 1 || batch > h->n->max_batch) { elfhip_set_error("net_forward: batch %d not in [1,%d]", batch, h->n->max_batch); return ELFHIP_EINVAL; }
+  return h->n->forward(d_s, batch, d_pi, d_logpi, d_v);
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+"""Host side of the policy/value network: packs a reference-format state_dict
+(model_american_checkers.py key names) into the flat blob `elfhip_net_load` takes, and wraps
+`elfhip_net_forward`.  Mirrors Model_PolicyValue.forward's return dict (`pi`, `logpi`, `V`)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import NetConfig, check
+
+
+def state_dict_order(num_block):
+    keys = []
+
+    def conv(prefix):
+        keys.extend([prefix + ".0.weight", prefix + ".0.bias", prefix + ".1.weight", prefix + ".1.bias",
+                     prefix + ".1.running_mean", prefix + ".1.running_var"])
+
+    conv("init_conv")
+    for k in range(num_block):
+        conv("resnet.resnet.%d.conv_lower" % k)
+        conv("resnet.resnet.%d.conv_upper" % k)
+    conv("pi_final_conv")
+    conv("value_final_conv")
+    keys += ["pi_linear.weight", "pi_linear.bias", "value_linear1.weight", "value_linear1.bias",
+             "value_linear2.weight", "value_linear2.bias"]
+    return keys
+
+
+def pack_state_dict(sd, num_block):
+    """Flatten in the documented order; strips an optional DataParallel 'module.' infix/prefix
+    (the reference does this with --replace_prefix, start_selfplay.sh:60-61)."""
+    clean = {}
+    for k, v in sd.items():
+        k = k.replace("module.", "")
+        clean[k] = v
+    parts = [clean[k].detach().to(torch.float32).cpu().reshape(-1).numpy() for k in state_dict_order(num_block)]
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+
+
+class PolicyValueNet:
+    def __init__(self, planes=36, board=8, dim=128, num_block=10, num_action=170, bn_eps=1e-5, max_batch=4096, device=0):
+        self.L = _lib.lib()
+        self.cfg = NetConfig(planes, board, dim, num_block, num_action, bn_eps)
+        self.max_batch = max_batch
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p()
+        check(self.L.elfhip_net_create(C.byref(self.cfg), max_batch, device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.elfhip_net_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream):
+        check(self.L.elfhip_net_set_stream(self.h, C.c_void_p(stream.cuda_stream if stream is not None else 0)))
+
+    def load_state_dict(self, sd):
+        blob = pack_state_dict(sd, self.cfg.num_block)
+        assert blob.size == self.L.elfhip_net_param_count(C.byref(self.cfg)), (blob.size,)
+        check(self.L.elfhip_net_load(self.h, blob.ctypes.data_as(C.c_void_p), blob.size))
+
+    def forward(self, s, want_logpi=False):
+        """s: float32 cuda [B, planes, board, board] -> dict(pi [B,A], V [B,1] (+ logpi))"""
+        assert s.dtype == torch.float32 and s.is_cuda and s.is_contiguous()
+        B = s.shape[0]
+        pi = torch.empty((B, self.cfg.num_action), dtype=torch.float32, device=self.device)
+        lp = torch.empty_like(pi) if want_logpi else None
+        v = torch.empty((B, 1), dtype=torch.float32, device=self.device)
+        check(self.L.elfhip_net_forward(self.h, s.data_ptr(), B, pi.data_ptr(), lp.data_ptr() if want_logpi else None, v.data_ptr()))
+        out = dict(pi=pi, V=v)
+        if want_logpi:
+            out["logpi"] = lp
+        return out

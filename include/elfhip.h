@@ -168,6 +168,43 @@ int elfhip_mcts_advance(elfhip_mcts* m, const int16_t* d_actions);
 int elfhip_mcts_stats(elfhip_mcts* m, unsigned long long* h_stats4, int32_t* d_flags);
 
 /* ------------------------------------------------------------------------------------------------
+ * Policy/value network forward (eval mode), bf16 MFMA with fp32 accumulation.
+ * Replaces Model_PolicyValue.forward (src_py/elfgames/american_checkers/model_american_checkers.py
+ * :325-349): init_conv -> num_block x Block (:85-90) -> policy head (1x1 conv to ONE channel + BN +
+ * ReLU, Linear(H*W -> num_action), log-softmax, exp) and value head (1x1 conv + BN + ReLU,
+ * Linear(H*W -> 256) + ReLU, Linear(256 -> 1), tanh).  BatchNorm is folded with running statistics.
+ *
+ * elfhip_net_load takes ONE flat fp32 host array holding the reference state_dict tensors in this
+ * order (each tensor flattened row-major, `num_batches_tracked` omitted):
+ *   init_conv.0.weight [dim,planes,3,3], init_conv.0.bias, init_conv.1.{weight,bias,running_mean,running_var}
+ *   for k in 0..num_block-1:  resnet.resnet.k.conv_lower.0.{weight [dim,dim,3,3],bias}, conv_lower.1.{w,b,mean,var},
+ *                             resnet.resnet.k.conv_upper.0.{weight,bias}, conv_upper.1.{w,b,mean,var}
+ *   pi_final_conv.0.{weight [1,dim,1,1],bias}, pi_final_conv.1.{w,b,mean,var},
+ *   value_final_conv.0.{weight,bias}, value_final_conv.1.{w,b,mean,var},
+ *   pi_linear.{weight [num_action,H*W],bias}, value_linear1.{weight [256,H*W],bias}, value_linear2.{weight [1,256],bias}
+ * (elf_amd/net.py packs a torch state_dict, stripping an optional "module." prefix.)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int planes;      /* checkers_num_planes (36) / 18 for the Go build */
+  int board;       /* checkers_board_size (8) / 19 */
+  int dim;         /* 32, 64, 128, 224 or 256 */
+  int num_block;
+  int num_action;  /* checkers_num_action (170) / 362 */
+  float bn_eps;    /* 1e-5 */
+} elfhip_net_config;
+
+typedef struct elfhip_net elfhip_net;
+
+int elfhip_net_create(const elfhip_net_config* cfg, int max_batch, int device, elfhip_net** out);
+int elfhip_net_destroy(elfhip_net* n);
+int elfhip_net_set_stream(elfhip_net* n, void* hip_stream);
+long long elfhip_net_param_count(const elfhip_net_config* cfg);
+int elfhip_net_load(elfhip_net* n, const float* h_params, long long n_params);
+/* d_s: float [batch][planes][board][board] (the "s" key); outputs float: d_pi [batch][num_action],
+ * d_logpi (nullable) same shape, d_v [batch]. */
+int elfhip_net_forward(elfhip_net* n, const float* d_s, int batch, float* d_pi, float* d_logpi, float* d_v);
+
+/* ------------------------------------------------------------------------------------------------
  * Host-only hooks for the explicit libstdc++-order emulations the search kernels use
  * (elf_amd/csrc/stdorder.h).  No reference counterpart: they exist so CPU tests can compare the
  * emulations with the real std::sort / std::unordered_map.

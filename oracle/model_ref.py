@@ -1,0 +1,88 @@
+"""TEST INFRASTRUCTURE ONLY (oracle).  Plain-PyTorch fp32 restatement of the reference's
+Model_PolicyValue (src_py/elfgames/american_checkers/model_american_checkers.py:21-349), written from
+the source text because the reference package cannot be imported here (`import elf` needs the
+compiled `_elf` extension, SURVEY.md 8c - an ordinary ModuleNotFoundError, nothing was denied).
+Module / parameter names reproduce the reference state_dict keys (init_conv.0/1,
+resnet.resnet.<k>.conv_lower.0/1, conv_upper.0/1, pi_final_conv.0/1, value_final_conv.0/1, pi_linear,
+value_linear1/2) so real checkpoints map one to one.  No pretrained weights exist in the container:
+parity fixtures use seeded random weights.
+"""
+import torch
+import torch.nn as nn
+
+
+def _conv_layer(cin, cout, kernel=3, relu=True, eps=1e-5, momentum=0.1):
+    layers = [nn.Conv2d(cin, cout, kernel, padding=kernel // 2), nn.BatchNorm2d(cout, momentum=momentum, eps=eps)]
+    if relu:
+        layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+class Block(nn.Module):  # :21-90
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.relu = nn.ReLU()
+        self.conv_lower = _conv_layer(dim, dim, eps=eps)
+        self.conv_upper = _conv_layer(dim, dim, relu=False, eps=eps)
+
+    def forward(self, s):
+        s1 = self.conv_upper(self.conv_lower(s))
+        return self.relu(s1 + s)
+
+
+class GoResNet(nn.Module):  # :102-125
+    def __init__(self, dim, num_block, eps):
+        super().__init__()
+        self.resnet = nn.Sequential(*[Block(dim, eps) for _ in range(num_block)])
+
+    def forward(self, s):
+        return self.resnet(s)
+
+
+class ModelPolicyValue(nn.Module):  # :137-349
+    def __init__(self, planes=36, board=8, dim=128, num_block=10, num_action=170, bn_eps=1e-5):
+        super().__init__()
+        self.board = board
+        self.relu = nn.ReLU()
+        self.init_conv = _conv_layer(planes, dim, eps=bn_eps)
+        self.pi_final_conv = _conv_layer(dim, 1, kernel=1, eps=bn_eps)
+        self.value_final_conv = _conv_layer(dim, 1, kernel=1, eps=bn_eps)
+        d = board * board
+        self.pi_linear = nn.Linear(d, num_action)
+        self.value_linear1 = nn.Linear(d, 256)
+        self.value_linear2 = nn.Linear(256, 1)
+        self.logsoftmax = nn.LogSoftmax(dim=1)
+        self.tanh = nn.Tanh()
+        self.resnet = GoResNet(dim, num_block, bn_eps)
+
+    def forward(self, s):  # :325-349
+        s = self.resnet(self.init_conv(s))
+        d = self.board ** 2
+        pi = self.pi_linear(self.pi_final_conv(s).view(-1, d))
+        logpi = self.logsoftmax(pi)
+        V = self.value_final_conv(s)
+        V = self.relu(self.value_linear1(V.view(-1, d)))
+        V = self.tanh(self.value_linear2(V))
+        return dict(logpi=logpi, pi=logpi.exp(), V=V)
+
+
+def seeded_model(seed=0, randomize_bn=True, head_gain=10.0, **cfg):
+    """Kaiming-default init under torch.manual_seed(seed); BN running stats / affine perturbed so that
+    BatchNorm folding is actually exercised (running stats = (0,1) would make folding trivial)."""
+    torch.manual_seed(seed)
+    m = ModelPolicyValue(**cfg)
+    if randomize_bn:
+        g = torch.Generator().manual_seed(seed + 1)
+        for mod in m.modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.num_features, generator=g) * 0.5 + 0.75)
+                mod.weight.data.copy_(torch.rand(mod.num_features, generator=g) * 0.5 + 0.75)
+                mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+    # default-init heads give an almost uniform pi and V ~ 0, which any implementation would match to
+    # 1e-2; sharpen them so the parity fixtures discriminate
+    with torch.no_grad():
+        m.pi_linear.weight.mul_(head_gain)
+        m.value_linear1.weight.mul_(head_gain ** 0.5)
+        m.value_linear2.weight.mul_(head_gain ** 0.5)
+    return m.eval()
