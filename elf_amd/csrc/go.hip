@@ -214,7 +214,28 @@ __device__ inline void go_forward(GoS& s, bool act, uint32_t a, ulonglong2* tab,
 // ---- SoA storage: rows [57][n] (B, W, AT), meta [4][n], hash [n], gen [n], table [n][1024] -------
 struct GoDev {
   uint32_t* rows; uint32_t* meta; uint64_t* hash; uint64_t* gen; ulonglong2* table; int n;
+  uint32_t* hist;   // [8 slots][38 rows (19 black, 19 white)][n]: stone snapshots for the 18 planes
+  uint32_t* hmeta;  // [n]: len (1..8) | head << 4   (ring; newest = (head + len - 1) % 8)
 };
+
+// stone history of GoState (8 most recent positions, oracle/go.c push_stones)
+__device__ inline void go_hist_write(const GoDev& d, int b, int slot, const GoS& s) {
+  ROWS(i) {
+    d.hist[((size_t)slot * 38 + i) * d.n + b] = s.tm ? s.Q[i] : s.P[i];
+    d.hist[((size_t)slot * 38 + 19 + i) * d.n + b] = s.tm ? s.P[i] : s.Q[i];
+  }
+}
+__device__ inline void go_hist_set_single(const GoDev& d, int b, const GoS& s) {
+  go_hist_write(d, b, 0, s);
+  d.hmeta[b] = 1u;
+}
+__device__ inline void go_hist_push(const GoDev& d, int b, const GoS& s) {
+  uint32_t m = d.hmeta[b];
+  int len = m & 15, head = (m >> 4) & 7, slot;
+  if (len < 8) { slot = (head + len) & 7; ++len; } else { slot = head; head = (head + 1) & 7; }
+  go_hist_write(d, b, slot, s);
+  d.hmeta[b] = (uint32_t)len | ((uint32_t)head << 4);
+}
 
 __device__ inline void go_load(const GoDev& d, int b, GoS& s) {
   const size_t n = d.n;
@@ -286,6 +307,7 @@ __global__ void __launch_bounds__(64) go_reset_kernel(GoDev d) {
   uint64_t gen = d.gen[b] + 1;
   d.gen[b] = gen;
   go_table_test_and_insert(d.table + (size_t)b * TAB_SLOTS, gen, 0);  // the empty start position
+  go_hist_set_single(d, b, s);
 }
 
 __global__ void __launch_bounds__(64) go_import_kernel(GoDev d, const uint64_t* __restrict__ aos) {
@@ -311,6 +333,7 @@ __global__ void __launch_bounds__(64) go_import_kernel(GoDev d, const uint64_t* 
     uint64_t gen = d.gen[b] + 1;
     d.gen[b] = gen;
     go_table_test_and_insert(d.table + (size_t)b * TAB_SLOTS, gen, s.hash);
+    go_hist_set_single(d, b, s);
   }
 }
 
@@ -376,7 +399,7 @@ __global__ void __launch_bounds__(64) go_step_kernel(GoDev d, const uint64_t* __
   }
   uint64_t gen = valid ? d.gen[b] : 0;
   go_forward(s, good, (uint32_t)(a < 0 ? 0 : a), d.table + (size_t)(valid ? b : 0) * TAB_SLOTS, gen, z);
-  if (good) go_store(d, b, s);
+  if (good) { go_store(d, b, s); go_hist_push(d, b, s); }
   if (valid && ok) ok[b] = good ? 1 : 0;
 }
 
@@ -423,7 +446,7 @@ go_playout_kernel(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t s
     go_forward(s, act, a, tab, gen, z);
     moves += act ? 1 : 0;
   }
-  if (valid) { go_store(d, b, s); d.gen[b] = gen; }
+  if (valid) { go_store(d, b, s); d.gen[b] = gen; go_hist_set_single(d, b, s); }  // playouts keep no plane history
   if (moves_out) {
     for (int o = 32; o > 0; o >>= 1) moves += __shfl_down(moves, o);
     if ((threadIdx.x & 63) == 0) atomicAdd(moves_out, moves);
@@ -451,13 +474,65 @@ __global__ void __launch_bounds__(64) go_evaluate_kernel(GoDev d, float* __restr
   }
 }
 
+// 18 AGZ-style planes (oracle/go.c go_features): 2i = side-to-move's stones i plies ago, 2i+1 = the
+// opponent's (i = 0..7, zero when the game is younger), 16 / 17 = all ones if black / white is to move.
+// One workgroup per board, thread = point.  BITS form: u64 [18][6], bit r*19+c.
+template <int DTYPE>
+__global__ void __launch_bounds__(384) go_features_kernel(GoDev d, void* __restrict__ out) {
+  __shared__ unsigned long long sbits[18 * 6];
+  const int b = blockIdx.x, p = threadIdx.x;
+  const size_t n = d.n;
+  const uint32_t tm = d.meta[b] & 1;
+  const uint32_t hm = d.hmeta[b];
+  const int len = hm & 15, head = (hm >> 4) & 7;
+  const int r = p / 19, c = p % 19;
+  if (DTYPE == ELFHIP_BITS) { if (p < 18 * 6) sbits[p] = 0; __syncthreads(); }
+  for (int i = 0; i < 8; ++i) {
+    float own = 0.f, opp = 0.f;
+    if (p < GO_POINTS && i < len) {
+      const int slot = (head + len - 1 - i) & 7;
+      const uint32_t bl = d.hist[((size_t)slot * 38 + r) * n + b], wh = d.hist[((size_t)slot * 38 + 19 + r) * n + b];
+      const uint32_t o = tm ? wh : bl, q = tm ? bl : wh;
+      own = (float)((o >> c) & 1); opp = (float)((q >> c) & 1);
+    }
+    if (p < GO_POINTS) {
+      if (DTYPE == ELFHIP_F32) {
+        ((float*)out)[((size_t)b * 18 + 2 * i) * GO_POINTS + p] = own;
+        ((float*)out)[((size_t)b * 18 + 2 * i + 1) * GO_POINTS + p] = opp;
+      } else if (DTYPE == ELFHIP_BF16) {
+        ((uint16_t*)out)[((size_t)b * 18 + 2 * i) * GO_POINTS + p] = own != 0.f ? 0x3F80 : 0;
+        ((uint16_t*)out)[((size_t)b * 18 + 2 * i + 1) * GO_POINTS + p] = opp != 0.f ? 0x3F80 : 0;
+      } else {
+        if (own != 0.f) atomicOr(&sbits[(2 * i) * 6 + (p >> 6)], 1ull << (p & 63));
+        if (opp != 0.f) atomicOr(&sbits[(2 * i + 1) * 6 + (p >> 6)], 1ull << (p & 63));
+      }
+    }
+  }
+  if (p < GO_POINTS) {
+    const float bk = tm == 0 ? 1.f : 0.f, wk = tm == 1 ? 1.f : 0.f;
+    if (DTYPE == ELFHIP_F32) {
+      ((float*)out)[((size_t)b * 18 + 16) * GO_POINTS + p] = bk;
+      ((float*)out)[((size_t)b * 18 + 17) * GO_POINTS + p] = wk;
+    } else if (DTYPE == ELFHIP_BF16) {
+      ((uint16_t*)out)[((size_t)b * 18 + 16) * GO_POINTS + p] = bk != 0.f ? 0x3F80 : 0;
+      ((uint16_t*)out)[((size_t)b * 18 + 17) * GO_POINTS + p] = wk != 0.f ? 0x3F80 : 0;
+    } else {
+      atomicOr(&sbits[(16 + tm) * 6 + (p >> 6)], 1ull << (p & 63));
+    }
+  }
+  if (DTYPE == ELFHIP_BITS) {
+    __syncthreads();
+    if (p < 18 * 6) ((unsigned long long*)out)[(size_t)b * 18 * 6 + p] = sbits[p];
+  }
+}
+
 struct GoSlab : BoardSlab {
   GoDev d{};
   uint64_t* gz = nullptr;   // Zobrist table [2*361]
   uint64_t* aos = nullptr;  // [n][22] staging
   ~GoSlab() override {
     (void)hipFree(d.rows); (void)hipFree(d.meta); (void)hipFree(d.hash); (void)hipFree(d.gen);
-    (void)hipFree(d.table); (void)hipFree(gz); (void)hipFree(aos);
+    (void)hipFree(d.table); (void)hipFree(gz); (void)hipFree(aos); (void)hipFree(d.hist); (void)hipFree(d.hmeta);
   }
   int grid() const { return (n + 63) / 64; }
   int alloc() override {
@@ -469,6 +544,8 @@ struct GoSlab : BoardSlab {
         hipMalloc(&d.gen, sizeof(uint64_t) * N) != hipSuccess ||
         hipMalloc(&d.table, sizeof(ulonglong2) * TAB_SLOTS * N) != hipSuccess ||
         hipMalloc(&gz, sizeof(uint64_t) * 2 * GO_POINTS) != hipSuccess ||
+        hipMalloc(&d.hist, sizeof(uint32_t) * 8 * 38 * N) != hipSuccess ||
+        hipMalloc(&d.hmeta, sizeof(uint32_t) * N) != hipSuccess ||
         hipMalloc(&aos, sizeof(uint64_t) * GO_WORDS * N) != hipSuccess) {
       elfhip_set_error("go19: device allocation of %d boards failed (needs %.1f MB)", n,
                        (double)N * (sizeof(ulonglong2) * TAB_SLOTS + 600) / 1e6);
@@ -510,9 +587,13 @@ struct GoSlab : BoardSlab {
     HIPCHECK(hipGetLastError());
     return ELFHIP_OK;
   }
-  int features(void*, int) override {
-    elfhip_set_error("go19 features: not built yet");
-    return ELFHIP_ESTATE;
+  int features(void* d_out, int dtype) override {
+    if (dtype == ELFHIP_F32) hipLaunchKernelGGL(go_features_kernel<ELFHIP_F32>, dim3(n), dim3(384), 0, stream, d, d_out);
+    else if (dtype == ELFHIP_BF16) hipLaunchKernelGGL(go_features_kernel<ELFHIP_BF16>, dim3(n), dim3(384), 0, stream, d, d_out);
+    else if (dtype == ELFHIP_BITS) hipLaunchKernelGGL(go_features_kernel<ELFHIP_BITS>, dim3(n), dim3(384), 0, stream, d, d_out);
+    else { elfhip_set_error("go19 features: unknown dtype %d", dtype); return ELFHIP_EINVAL; }
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
   }
   int evaluate(float* d_value) override {
     hipLaunchKernelGGL(go_evaluate_kernel, dim3(grid()), dim3(64), 0, stream, d, d_value, (float*)nullptr);

@@ -153,3 +153,48 @@ def test_full_size_properties(torch_cuda):
         m = g.mask()
         ko = (int(s[b, 20]) >> 32) & 0xFFFF
         assert np.array_equal(mask[b], m), b
+
+
+def test_feature_planes_vs_oracle(torch_cuda):
+    """18 planes (8-deep stone history x 2 + colour planes), f32 / bf16 / bit-packed, incl. passes,
+    young games (short history) and boards imported mid-game."""
+    torch = torch_cuda
+    from elf_amd.boards import BoardBatch, GO19, F32, BF16, BITS
+    n = 48
+    bb = BoardBatch(GO19, n)
+    g = GoBoards(n)
+    rng = np.random.default_rng(23)
+
+    def check(tag):
+        f = bb.extract(F32).cpu().numpy()
+        h = bb.extract(BF16).float().cpu().numpy()
+        bits = bb.extract(BITS).cpu().numpy().view(np.uint64).reshape(n, 18, 6)
+        for b in range(n):
+            ref = g.features(b)
+            assert np.array_equal(f[b], ref), (tag, b)
+            assert np.array_equal(h[b], ref), (tag, b)
+            flat = ref.reshape(18, 361)
+            for pl in range(18):
+                w = np.zeros(6, dtype=np.uint64)
+                for p in np.nonzero(flat[pl])[0]:
+                    w[p >> 6] |= np.uint64(1) << np.uint64(p & 63)
+                assert np.array_equal(bits[b, pl], w), (tag, b, pl)
+
+    check("start")
+    for ply in range(40):
+        acts = np.full(n, -1, dtype=np.int16)
+        for b in range(n):
+            if g.terminated(b) or b > ply * 3:      # staggered starts -> different history lengths
+                continue
+            legal = [a for a in g.legal(b) if a != GO_PASS]
+            acts[b] = GO_PASS if (rng.random() < 0.05 or not legal) else legal[rng.integers(len(legal))]
+            assert g.forward(int(acts[b]), b)
+        bb.forward(torch.tensor(acts, device="cuda"))
+        if ply in (0, 1, 5, 7, 8, 9, 20, 39):
+            check(ply)
+    # import resets the plane history to the single imported position (oracle go_import does the same)
+    st = g.export_all()
+    bb.import_states(st)
+    for b in range(n):
+        g.load(st[b], b)
+    check("import")
