@@ -16,12 +16,12 @@ F32, BF16, BITS = 0, 1, 2
 SYMBOLS = [
     "elfhip_last_error", "elfhip_device_count", "elfhip_abi_version", "elfhip_game_get_info",
     "elfhip_boards_create", "elfhip_boards_destroy", "elfhip_boards_set_stream", "elfhip_boards_count",
-    "elfhip_boards_game", "elfhip_boards_reset", "elfhip_boards_export", "elfhip_boards_import",
+    "elfhip_boards_game", "elfhip_boards_reset", "elfhip_boards_reset_mask", "elfhip_boards_export", "elfhip_boards_import",
     "elfhip_boards_legal_mask", "elfhip_boards_step", "elfhip_boards_features", "elfhip_boards_evaluate",
     "elfhip_boards_playout", "elfhip_test_sort_order", "elfhip_test_umap_order",
     "elfhip_mcts_create", "elfhip_mcts_destroy", "elfhip_mcts_set_stream", "elfhip_mcts_clear", "elfhip_mcts_set_roots",
     "elfhip_mcts_run_uniform", "elfhip_mcts_select", "elfhip_mcts_backup", "elfhip_mcts_result", "elfhip_mcts_advance",
-    "elfhip_mcts_stats",
+    "elfhip_mcts_stats", "elfhip_mcts_pick_moves",
     "elfhip_net_create", "elfhip_net_destroy", "elfhip_net_set_stream", "elfhip_net_param_count", "elfhip_net_load",
     "elfhip_net_forward",
 ]
@@ -70,6 +70,7 @@ def lib():
     L.elfhip_boards_count.argtypes = [vp]
     L.elfhip_boards_game.argtypes = [vp]
     L.elfhip_boards_reset.argtypes = [vp]
+    L.elfhip_boards_reset_mask.argtypes = [vp, vp]
     L.elfhip_boards_export.argtypes = [vp, vp]
     L.elfhip_boards_import.argtypes = [vp, vp]
     L.elfhip_boards_legal_mask.argtypes = [vp, vp, vp]
@@ -89,6 +90,7 @@ def lib():
     L.elfhip_mcts_backup.argtypes = [vp, vp, vp]
     L.elfhip_mcts_result.argtypes = [vp] + [vp] * 9 + [i, vp]
     L.elfhip_mcts_advance.argtypes = [vp, vp]
+    L.elfhip_mcts_pick_moves.argtypes = [vp, vp, i, u64, u64, vp, vp, vp]
     L.elfhip_mcts_stats.argtypes = [vp, vp, vp]
     L.elfhip_net_create.argtypes = [C.POINTER(NetConfig), i, i, C.POINTER(vp)]
     L.elfhip_net_destroy.argtypes = [vp]

@@ -46,9 +46,9 @@ __device__ inline void am_hist_push(uint64_t* hist, uint32_t* hmeta, int n, int 
 }
 
 // ---- kernels ------------------------------------------------------------------------------------
-__global__ void am_reset_kernel(uint64_t* w, uint64_t* hist, uint32_t* hmeta, int n) {
+__global__ void am_reset_kernel(uint64_t* w, uint64_t* hist, uint32_t* hmeta, int n, const uint8_t* __restrict__ which) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n) return;
+  if (b >= n || (which && !which[b])) return;
   Am s; am_clear(s);
   am_store(w, n, b, s);
   am_hist_set_single(hist, hmeta, n, b, s);
@@ -236,7 +236,12 @@ struct AmericanSlab : BoardSlab {
   }
   int reset() override {
     step_counter = 0;
-    hipLaunchKernelGGL(am_reset_kernel, dim3(grid()), dim3(256), 0, stream, w, hist, hmeta, n);
+    hipLaunchKernelGGL(am_reset_kernel, dim3(grid()), dim3(256), 0, stream, w, hist, hmeta, n, (const uint8_t*)nullptr);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  int reset_mask(const uint8_t* d_which) override {
+    hipLaunchKernelGGL(am_reset_kernel, dim3(grid()), dim3(256), 0, stream, w, hist, hmeta, n, d_which);
     HIPCHECK(hipGetLastError());
     return ELFHIP_OK;
   }

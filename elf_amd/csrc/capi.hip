@@ -98,6 +98,12 @@ int elfhip_boards_game(const elfhip_boards* b) { return (b && b->slab) ? b->slab
 
 int elfhip_boards_reset(elfhip_boards* b) { CHECK_H(b); return b->slab->reset(); }
 
+int elfhip_boards_reset_mask(elfhip_boards* b, const uint8_t* d_which) {
+  CHECK_H(b);
+  if (!d_which) { elfhip_set_error("boards_reset_mask: null d_which"); return ELFHIP_EINVAL; }
+  return b->slab->reset_mask(d_which);
+}
+
 int elfhip_boards_export(elfhip_boards* b, uint64_t* h_states) {
   CHECK_H(b);
   if (!h_states) { elfhip_set_error("boards_export: null buffer"); return ELFHIP_EINVAL; }

@@ -44,6 +44,7 @@ struct BoardSlab {
   virtual ~BoardSlab() {}
   virtual int alloc() = 0;
   virtual int reset() = 0;
+  virtual int reset_mask(const uint8_t* d_which) = 0;  // reset only boards with d_which[i] != 0
   virtual int export_states(uint64_t* h) = 0;
   virtual int import_states(const uint64_t* h) = 0;
   virtual int legal_mask(uint64_t* d_mask, uint8_t* d_terminal) = 0;

@@ -299,9 +299,9 @@ __global__ void go_zobrist_init_kernel(uint64_t* gz) {
   if (i < 2 * GO_POINTS) gz[i] = elf_splitmix64(GO_ZSEED + (uint64_t)i);
 }
 
-__global__ void __launch_bounds__(64) go_reset_kernel(GoDev d) {
+__global__ void __launch_bounds__(64) go_reset_kernel(GoDev d, const uint8_t* __restrict__ which) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= d.n) return;
+  if (b >= d.n || (which && !which[b])) return;
   GoS s; go_clear(s);
   go_store(d, b, s);
   uint64_t gen = d.gen[b] + 1;
@@ -559,7 +559,12 @@ struct GoSlab : BoardSlab {
   }
   int reset() override {
     step_counter = 0;
-    hipLaunchKernelGGL(go_reset_kernel, dim3(grid()), dim3(64), 0, stream, d);
+    hipLaunchKernelGGL(go_reset_kernel, dim3(grid()), dim3(64), 0, stream, d, (const uint8_t*)nullptr);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  int reset_mask(const uint8_t* d_which) override {
+    hipLaunchKernelGGL(go_reset_kernel, dim3(grid()), dim3(64), 0, stream, d, d_which);
     HIPCHECK(hipGetLastError());
     return ELFHIP_OK;
   }

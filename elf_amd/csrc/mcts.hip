@@ -445,6 +445,60 @@ mcts_result_kernel(TreeDev d, int pick, int16_t* __restrict__ best_out, int32_t*
   }
 }
 
+// mcts_make_diverse_move / mcts_update_info (ClientGameSelfPlay.cc:94-122) + addMCTSPolicy
+// (GameStateExt.h:79-100) + MCTSPolicy::normalize (tree_search_base.h:251-262)
+__global__ void __launch_bounds__(64)
+mcts_pick_kernel(TreeDev d, const int32_t* __restrict__ ply, int cutoff, uint64_t seed, uint64_t counter,
+                 int16_t* __restrict__ move, uint8_t* __restrict__ pol, float* __restrict__ value) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  TV tv = tree_view(d, t, d.t_arena[t]);
+  const uint32_t meta = tv.meta[0];
+  const int ne = (meta & 0xFF) == VISITED ? (int)(meta >> 16) : 0;
+  const int eb = (int)tv.ebase[0];
+  if (pol) for (int a = lane; a < NA; a += 64) pol[(size_t)t * NA + a] = 0;
+  __syncthreads();
+  // pass 1: totals, most-visited edge (first strict max in edge order)
+  int total = 0, bestv = -1, bestj = 0x7FFFFFFF;
+  for (int base = 0; base < ne; base += 64) {
+    const int j = base + lane;
+    int v = j < ne ? tv.ev[eb + j] : -1, vj = j < ne ? j : 0x7FFFFFFF, sum = j < ne ? v : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      int v2 = __shfl_xor(v, off), j2 = __shfl_xor(vj, off);
+      if (v2 > v || (v2 == v && j2 < vj)) { v = v2; vj = j2; }
+      sum += __shfl_xor(sum, off);
+    }
+    if (v > bestv || (v == bestv && vj < bestj)) { bestv = v; bestj = vj; }
+    total += sum;
+  }
+  const bool diverse = ply && ply[t] <= cutoff && total > 0;
+  const uint64_t r = diverse ? elf_splitmix64(seed + (uint64_t)t * ELF_GOLDEN + counter) % (uint64_t)total : 0;
+  const float exp_sum = (float)total, maxp = total > 0 ? (float)bestv / exp_sum : 0.f;
+  int chosen = ne > 0 ? bestj : -1, cum = 0;
+  bool picked = false;
+  for (int base = 0; base < ne; base += 64) {
+    const int j = base + lane;
+    const int v = j < ne ? tv.ev[eb + j] : 0;
+    if (pol && j < ne) {
+      const float p = (float)v / exp_sum;
+      const float q = p / maxp * 255.0f;
+      pol[(size_t)t * NA + tv.ea[eb + j]] = total > 0 ? (uint8_t)q : 0;
+    }
+    if (diverse && !picked) {
+      int incl = v;  // inclusive prefix sum over the wave
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { int x = __shfl_up(incl, off); if (lane >= off) incl += x; }
+      const unsigned long long hit = __ballot(j < ne && (uint64_t)(cum + incl) > r);
+      if (hit) { chosen = base + (__ffsll((long long)hit) - 1); picked = true; }
+      cum += __shfl(incl, 63);
+    }
+  }
+  if (lane == 0) {
+    move[t] = chosen < 0 ? (int16_t)-1 : (int16_t)tv.ea[eb + chosen];
+    if (value) value[t] = (ne == 0 || total == 0) ? tv.V[0] : tv.er[eb + bestj] / (float)tv.ev[eb + bestj];
+  }
+}
+
 // TreeT::treeAdvance tree_search_node.h:458-474: keep the chosen child's subtree, drop the rest.
 // The kept subtree is copied breadth-first into the other arena (new indices, same contents).
 __global__ void __launch_bounds__(64) mcts_advance_kernel(TreeDev d, const int16_t* __restrict__ actions) {
@@ -660,6 +714,17 @@ int elfhip_mcts_result(elfhip_mcts* h, int16_t* d_best, int32_t* d_total_visits,
   hipLaunchKernelGGL(mcts_result_kernel, dim3(m->d.n_trees), dim3(64), 0, m->stream, m->d, m->o.pick, d_best, d_total_visits,
                      d_best_q, d_root_value, d_n_edges, d_edge_action, d_edge_visits, d_edge_reward, d_edge_prior, edge_cap,
                      d_policy_visits);
+  HIPCHECK(hipGetLastError());
+  return ELFHIP_OK;
+}
+
+int elfhip_mcts_pick_moves(elfhip_mcts* h, const int32_t* d_ply, int policy_distri_cutoff, uint64_t seed, uint64_t counter,
+                           int16_t* d_move, uint8_t* d_policy_u8, float* d_value) {
+  CHECK_M(h);
+  if (!d_move) { elfhip_set_error("mcts_pick_moves: null d_move"); return ELFHIP_EINVAL; }
+  MctsImpl* m = h->m;
+  hipLaunchKernelGGL(mcts_pick_kernel, dim3(m->d.n_trees), dim3(64), 0, m->stream, m->d, d_ply, policy_distri_cutoff, seed,
+                     counter, d_move, d_policy_u8, d_value);
   HIPCHECK(hipGetLastError());
   return ELFHIP_OK;
 }

@@ -1,0 +1,92 @@
+"""Batched self-play driver: the GPU counterpart of ClientGameSelfPlay::act
+(src_cpp/elfgames/american_checkers/common/ClientGameSelfPlay.cc:249-375) for n games at once.
+
+Per move (all games in lock-step): MCTSAI_T::act (set root, rollouts, chooseAction) ->
+mcts_make_diverse_move / addMCTSPolicy (uint8-quantised visit policy) -> mcts_update_info
+(predicted value) -> GameState::forward -> on terminal: setFinalValue, endGame (tree reset), record,
+restart.  Game records are fixed-stride slabs (DESIGN.md / SURVEY.md 8e) instead of the reference's JSON.
+Everything numeric runs in libelfhip.so; torch only holds buffers and does index bookkeeping."""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+from .boards import BoardBatch
+from .mcts import TreeSearchBatch
+
+
+class SelfPlayBatch:
+    def __init__(self, game, n_games, device=0, net=None, policy_distri_cutoff=0, seed=0, keep_policies=True,
+                 **ts_kwargs):
+        self.game, self.n = game, int(n_games)
+        self.device = torch.device("cuda", device)
+        self.bb = BoardBatch(game, self.n, device)
+        self.ts = TreeSearchBatch(game, self.n, device, **ts_kwargs)
+        self.net = net
+        self.cutoff, self.seed, self.counter = int(policy_distri_cutoff), int(seed), 0
+        info = self.bb.info
+        self.A, self.max_ply = info.num_actions, info.max_ply
+        dev = self.device
+        self.ply = torch.ones(self.n, dtype=torch.int32, device=dev)           # GameState::getPly starts at 1
+        self.nmoves = torch.zeros(self.n, dtype=torch.int64, device=dev)
+        self.moves = torch.full((self.n, self.max_ply), -1, dtype=torch.int16, device=dev)
+        self.values = torch.zeros((self.n, self.max_ply), dtype=torch.float32, device=dev)
+        self.policies = torch.zeros((self.n, self.max_ply, self.A), dtype=torch.uint8, device=dev) if keep_policies else None
+        self.seq = torch.zeros(self.n, dtype=torch.int64, device=dev)          # games finished per slot
+        self._move = torch.empty(self.n, dtype=torch.int16, device=dev)
+        self._val = torch.empty(self.n, dtype=torch.float32, device=dev)
+        self._pol = torch.empty((self.n, self.A), dtype=torch.uint8, device=dev) if keep_policies else None
+        self.finished = []   # list of record slabs (dict of numpy arrays), one per step that ended games
+        self.win_stats = dict(black_wins=0, white_wins=0, total_games=0, sum_reward=0.0)   # WinRateStats, GameStats.h:22-75
+
+    def _evaluate(self, feat, states, need):
+        out = self.net.forward(feat.contiguous())
+        return out["pi"], out["V"].reshape(-1)
+
+    def step(self):
+        """One move of every game.  Returns the number of games that finished."""
+        ts, bb = self.ts, self.bb
+        ts.set_roots(bb)
+        if self.net is None:
+            ts.run_uniform()
+        else:
+            ts.run(self._evaluate)
+        check(ts.L.elfhip_mcts_pick_moves(ts.h, self.ply.data_ptr(), self.cutoff, self.seed, self.counter,
+                                          self._move.data_ptr(), self._pol.data_ptr() if self._pol is not None else None,
+                                          self._val.data_ptr()))
+        self.counter += 1
+        idx = torch.arange(self.n, device=self.device)
+        self.moves[idx, self.nmoves] = self._move
+        self.values[idx, self.nmoves] = self._val
+        if self.policies is not None:
+            self.policies[idx, self.nmoves] = self._pol
+        ok = bb.forward(self._move)
+        ts.treeAdvance(self._move)
+        okl = ok.to(torch.int64)
+        self.nmoves += okl
+        self.ply += ok.to(torch.int32)
+        term = bb.terminated()
+        nfin = int(term.sum().item())
+        if nfin:
+            reward = bb.evaluateGame()                                        # setFinalValue
+            w = term.nonzero().flatten()
+            slab = dict(game_id=w.cpu().numpy().astype(np.int32), seq=self.seq[w].cpu().numpy(),
+                        n_moves=self.nmoves[w].cpu().numpy().astype(np.int32), reward=reward[w].cpu().numpy(),
+                        moves=self.moves[w].cpu().numpy(), values=self.values[w].cpu().numpy())
+            if self.policies is not None:
+                slab["policies"] = self.policies[w].cpu().numpy()
+            self.finished.append(slab)
+            r = slab["reward"]
+            self.win_stats["black_wins"] += int((r > 0).sum()); self.win_stats["white_wins"] += int((r < 0).sum())
+            self.win_stats["total_games"] += nfin; self.win_stats["sum_reward"] += float(r.sum())
+            ts.clear(term)                                                    # ai->endGame -> resetTree
+            check(bb.L.elfhip_boards_reset_mask(bb.h, term.data_ptr()))       # GameStateExt::restart
+            self.nmoves[w] = 0; self.ply[w] = 1; self.seq[w] += 1
+            self.moves[w] = -1; self.values[w] = 0
+            if self.policies is not None:
+                self.policies[w] = 0
+        return nfin
+
+    def take_records(self):
+        out, self.finished = self.finished, []
+        return out

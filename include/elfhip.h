@@ -72,6 +72,9 @@ int elfhip_boards_game(const elfhip_boards* b);
 
 /* GameState::reset (GameState.cc:24-30) on every board; clears history and counters. */
 int elfhip_boards_reset(elfhip_boards* b);
+/* The same for the boards with d_which[i] != 0 only (a finished game restarts in place:
+ * GameStateExt::restart, ClientGameSelfPlay.cc:124-145). */
+int elfhip_boards_reset_mask(elfhip_boards* b, const uint8_t* d_which);
 
 /* Copy all board states to / from a HOST buffer of n*state_words u64 (array-of-structs, layout in
  * DESIGN.md; for American checkers the 6 words of oracle/american.h).  Synchronises the stream.
@@ -160,6 +163,19 @@ int elfhip_mcts_backup(elfhip_mcts* m, const float* d_pi, const float* d_value);
 int elfhip_mcts_result(elfhip_mcts* m, int16_t* d_best, int32_t* d_total_visits, float* d_best_q, float* d_root_value,
                        int32_t* d_n_edges, int16_t* d_edge_action, int32_t* d_edge_visits, float* d_edge_reward,
                        float* d_edge_prior, int edge_cap, int32_t* d_policy_visits);
+/* Move choice and record values of the self-play loop (ClientGameSelfPlay.cc:94-122):
+ *   policy = MCTSGameAI::getMCTSPolicy (visit counts normalised, MCTSGameAI.h:48-54);
+ *   d_policy_u8 (nullable) u8 [n][num_actions] = GameStateExt::addMCTSPolicy quantisation
+ *     uchar(p / max_p * 255)  (GameStateExt.h:79-100);
+ *   d_value (nullable) f32 [n] = MCTSGameAI::getValue (best edge Q, or root V when unvisited);
+ *   d_move i16 [n] = chooseAction's best action, or, where d_ply[i] <= policy_distri_cutoff, an action
+ *     sampled in proportion to visit counts (mcts_make_diverse_move).  The reference samples with
+ *     std::mt19937 + std::uniform_real_distribution; here r = splitmix64(seed + tree*GOLDEN + counter)
+ *     mod total_visits over the cumulative counts in edge order - same distribution, different
+ *     stream, so sampled games are not bit-comparable (parity configs use cutoff 0).
+ * d_ply (nullable = never sample): i32 [n] current ply of each game (starts at 1 like getPly()). */
+int elfhip_mcts_pick_moves(elfhip_mcts* m, const int32_t* d_ply, int policy_distri_cutoff, uint64_t seed,
+                           uint64_t counter, int16_t* d_move, uint8_t* d_policy_u8, float* d_value);
 /* TreeSearchT::treeAdvance (tree_search_node.h:458-474) with d_actions i16 [n_trees] (negative = skip). */
 int elfhip_mcts_advance(elfhip_mcts* m, const int16_t* d_actions);
 /* Counters since creation: h_stats4 = {rollouts, network evaluations, sum of descent depths, edges

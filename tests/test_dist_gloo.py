@@ -1,0 +1,68 @@
+"""world_size-2 `gloo` tests (CPU) of the multi-GPU plumbing: game sharding, weight broadcast with
+version id, ragged record gather."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from elf_amd import dist as edist
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # weights: rank 0 publishes version 7
+        torch.manual_seed(0)
+        ref = torch.randn(1000)
+        flat = ref.clone() if rank == 0 else torch.zeros(1000)
+        flat, ver = edist.broadcast_weights(flat, 7 if rank == 0 else -1, src=0)
+        ok_w = bool(torch.equal(flat, ref)) and ver == 7
+        # records: rank 0 has 3 finished games, rank 1 has 0 first, then 2
+        res = []
+        for counts in ([3, 0], [1, 2]):
+            k = counts[rank]
+            slab = dict(game_id=torch.arange(k, dtype=torch.int32) + 100 * rank,
+                        moves=torch.full((k, 5), rank, dtype=torch.int16),
+                        reward=torch.full((k,), float(rank + 1)))
+            g = edist.gather_records(slab, dst=0)
+            if rank == 0:
+                res.append({n: v.numpy().tolist() for n, v in g.items()})
+            else:
+                assert g is None
+        q.put((rank, ok_w, res, edist.shard_games(10, rank, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_and_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, ok0, res0, sh0), (r1, ok1, res1, sh1) = outs
+    assert ok0 and ok1
+    assert sh0 == (0, 5) and sh1 == (5, 10)
+    assert res0[0]["game_id"] == [0, 1, 2] and res0[0]["reward"] == [1.0, 1.0, 1.0]
+    assert res0[1]["game_id"] == [0, 100, 101] and res0[1]["reward"] == [1.0, 2.0, 2.0]
+    assert res0[1]["moves"] == [[0] * 5, [1] * 5, [1] * 5]
+
+
+def test_shard_games_covers_everything():
+    for total in (0, 1, 7, 16384, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [edist.shard_games(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
