@@ -78,6 +78,23 @@ def oracle():
         L.go_playout.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]
         L.go_playout.restype = C.c_uint64
         L.go_sizeof_state.restype = C.c_int
+        # --- Russian checkers
+        L.ru_clear.argtypes = [_u64p]
+        L.ru_legal_mask.argtypes = [_u64p, _u64p]
+        L.ru_play.argtypes = [_u64p, C.c_int]
+        L.ru_is_over.argtypes = [_u64p]
+        L.ru_is_over.restype = C.c_int
+        L.ru_observation.argtypes = [_u64p, C.c_int, _i8p]
+        L.ru_action.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ru_terminated.argtypes = [_u64p]
+        L.ru_terminated.restype = C.c_int
+        L.ru_forward.argtypes = [_u64p, C.c_int]
+        L.ru_forward.restype = C.c_int
+        L.ru_evaluate.argtypes = [_u64p]
+        L.ru_evaluate.restype = C.c_float
+        L.ru_features.argtypes = [_u64p, _f32p]
+        L.ru_playout.argtypes = [_u64p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]
+        L.ru_playout.restype = C.c_uint64
         # --- MCTS restatement (oracle/mcts.cpp)
         _u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS")
         L.omcts_create.argtypes = [_i32p, C.c_float, C.c_int, C.c_uint64]
@@ -115,6 +132,27 @@ def ref():
         L.ref_am_action.argtypes = [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         _ref = L
     return _ref
+
+
+_ref_ru = None
+
+
+def ref_russian():
+    global _ref_ru
+    if _ref_ru is None:
+        path = os.path.join(ORACLE_DIR, "_ref", "libref_russian.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        L.ref_ru_clear.argtypes = [_u64p]
+        L.ref_ru_valid_moves.argtypes = [_u64p, _i32p]
+        L.ref_ru_play.argtypes = [_u64p, C.c_int]
+        L.ref_ru_is_over.argtypes = [_u64p]
+        L.ref_ru_is_over.restype = C.c_int
+        L.ref_ru_observation.argtypes = [_u64p, C.c_int, _i32p]
+        L.ref_ru_action.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _ref_ru = L
+    return _ref_ru
 
 
 # ---- small numpy helpers shared by tests -------------------------------------------------------
