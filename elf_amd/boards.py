@@ -37,8 +37,13 @@ class BoardBatch:
             pass
 
     # --- GameState API, batched ------------------------------------------------------------------
-    def reset(self):
-        check(self.L.elfhip_boards_reset(self.h))
+    def reset(self, which=None):
+        """Reset every board, or only those with which[i] != 0 ([n] uint8 cuda tensor)."""
+        if which is None:
+            check(self.L.elfhip_boards_reset(self.h))
+        else:
+            assert which.dtype == torch.uint8 and which.is_cuda and which.numel() == self.n
+            check(self.L.elfhip_boards_reset_mask(self.h, which.data_ptr()))
 
     def set_stream(self, stream):
         check(self.L.elfhip_boards_set_stream(self.h, C.c_void_p(stream.cuda_stream if stream is not None else 0)))

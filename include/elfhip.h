@@ -34,7 +34,10 @@ extern "C" {
 
 enum elfhip_game {
   ELFHIP_AMERICAN = 0, /* american_checkers: 170 actions, 6 state words, 36x8x8 planes */
-  ELFHIP_RUSSIAN = 1,  /* russian_checkers : 280 actions */
+  ELFHIP_RUSSIAN = 1,  /* russian_checkers : 280 actions, 5 state words (white pawns, white kings, black pawns,
+                          black kings as bit y*8+x; word 4 = player(1 white) | has_next<<1 | next_y<<2 |
+                          next_x<<5 | ply<<8 | last_move<<24), 6x8x8 planes
+                          (reference: russian_checkers/game/CheckersBoard.h:60-90, CheckersFeature.cc:57-82) */
   ELFHIP_UGOLKI = 2,   /* ugolki           : 418 actions */
   ELFHIP_GO19 = 3      /* Go 19x19         : 362 actions (361 points + pass), build-defined */
 };
