@@ -95,6 +95,26 @@ def oracle():
         L.ru_features.argtypes = [_u64p, _f32p]
         L.ru_playout.argtypes = [_u64p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]
         L.ru_playout.restype = C.c_uint64
+        # --- Ugolki
+        L.ug_clear.argtypes = [_u64p]
+        L.ug_legal_mask.argtypes = [_u64p, _u64p]
+        L.ug_try_play.argtypes = [_u64p, C.c_int]
+        L.ug_try_play.restype = C.c_int
+        L.ug_play.argtypes = [_u64p, C.c_int]
+        L.ug_is_over.argtypes = [_u64p]
+        L.ug_is_over.restype = C.c_int
+        L.ug_observation.argtypes = [_u64p, C.c_int, _i8p]
+        L.ug_action.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.ug_action.restype = C.c_int
+        L.ug_terminated.argtypes = [_u64p]
+        L.ug_terminated.restype = C.c_int
+        L.ug_forward.argtypes = [_u64p, C.c_int]
+        L.ug_forward.restype = C.c_int
+        L.ug_evaluate.argtypes = [_u64p]
+        L.ug_evaluate.restype = C.c_float
+        L.ug_features.argtypes = [_u64p, _f32p]
+        L.ug_playout.argtypes = [_u64p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]
+        L.ug_playout.restype = C.c_uint64
         # --- MCTS restatement (oracle/mcts.cpp)
         _u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS")
         L.omcts_create.argtypes = [_i32p, C.c_float, C.c_int, C.c_uint64]
@@ -153,6 +173,30 @@ def ref_russian():
         L.ref_ru_action.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _ref_ru = L
     return _ref_ru
+
+
+_ref_ug = None
+
+
+def ref_ugolki():
+    global _ref_ug
+    if _ref_ug is None:
+        path = os.path.join(ORACLE_DIR, "_ref", "libref_ugolki.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        L.ref_ug_clear.argtypes = [_u64p]
+        L.ref_ug_valid_moves.argtypes = [_u64p, _i32p]
+        L.ref_ug_play.argtypes = [_u64p, C.c_int]
+        L.ref_ug_tryplay.argtypes = [_u64p, C.c_int]
+        L.ref_ug_tryplay.restype = C.c_int
+        L.ref_ug_is_over.argtypes = [_u64p]
+        L.ref_ug_is_over.restype = C.c_int
+        L.ref_ug_observation.argtypes = [_u64p, C.c_int, _i32p]
+        L.ref_ug_action.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.ref_ug_action.restype = C.c_int
+        _ref_ug = L
+    return _ref_ug
 
 
 # ---- small numpy helpers shared by tests -------------------------------------------------------
