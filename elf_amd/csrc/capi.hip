@@ -38,6 +38,7 @@ int elfhip_game_get_info(int game, elfhip_game_info* out) {
   switch (game) {
     case ELFHIP_AMERICAN: *out = {170, 3, 6, 36, 8, 250}; return ELFHIP_OK;
     case ELFHIP_RUSSIAN: *out = {280, 5, 5, 6, 8, 250}; return ELFHIP_OK;
+    case ELFHIP_UGOLKI: *out = {418, 7, 4, 16, 8, 500}; return ELFHIP_OK;
     case ELFHIP_GO19: *out = {362, 6, 22, 18, 19, 722}; return ELFHIP_OK;
     default: elfhip_set_error("game_get_info: unknown or unbuilt game %d", game); return ELFHIP_EINVAL;
   }
@@ -61,6 +62,7 @@ int elfhip_boards_create(int game, int n_boards, int device, elfhip_boards** out
   switch (game) {
     case ELFHIP_AMERICAN: s = elfhip_make_american(); break;
     case ELFHIP_RUSSIAN: s = elfhip_make_russian(); break;
+    case ELFHIP_UGOLKI: s = elfhip_make_ugolki(); break;
     case ELFHIP_GO19: s = elfhip_make_go19(); break;
     default: break;
   }

@@ -59,3 +59,4 @@ struct elfhip_boards { BoardSlab* slab; };
 BoardSlab* elfhip_make_american();
 BoardSlab* elfhip_make_go19();
 BoardSlab* elfhip_make_russian();
+BoardSlab* elfhip_make_ugolki();

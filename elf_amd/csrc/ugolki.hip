@@ -1,0 +1,374 @@
+// Ugolki ("corners": 9 men a side, orthogonal steps and chained orthogonal jumps) on gfx950.
+// One lane owns one board; the state is 4 x u64 in registers (black men, white men, jump_action,
+// meta), struct-of-arrays in HBM.
+//
+// Behaviour follows /root/reference/src_cpp/elfgames/ugolki/game/GameBoard.cc (cited per function).
+// The reference builds a std::vector of {bits, flags} moves and resolves each through a
+// std::stringstream + std::map<string,int> (GameBoard.cc:113-129).  Here the eight move families
+// stay bitboards indexed by the LOW square of the two-square pattern; the reference's action table
+// (HashAllMoves.h) is exactly "family-major, low square ascending", so the 417-bit legal mask is
+// eight row-compressed bitboards packed end to end plus the pass bit - no loops over moves at all.
+#include "common.h"
+
+namespace {
+
+constexpr int UG_PASS = 416, UG_MAX_PLY = 500, UG_PLANES = 16;
+constexpr uint64_t UG_WHITE_BASE = 0xE0E0E00000000000ull, UG_BLACK_BASE = 0x0000000000070707ull;
+constexpr uint64_t UG_X0 = 0x0101010101010101ull;
+constexpr uint64_t UG_NOT_X7 = ~(UG_X0 << 7), UG_NOT_X67 = ~((UG_X0 << 7) | (UG_X0 << 6));
+constexpr uint64_t UG_NOT_X0 = ~UG_X0, UG_NOT_X01 = ~(UG_X0 | (UG_X0 << 1));
+
+struct Ug { uint64_t p[2], ja, meta; };  // meta = active | black_win<<1 | white_win<<4 | ply<<8
+
+__device__ inline int ug_active(const Ug& s) { return (int)(s.meta & 1); }
+__device__ inline int ug_ply(const Ug& s) { return (int)((s.meta >> 8) & 0xFFFF); }
+__device__ inline int ug_bwin(const Ug& s) { return (int)((s.meta >> 1) & 7); }
+__device__ inline int ug_wwin(const Ug& s) { return (int)((s.meta >> 4) & 7); }
+__device__ inline bool ug_over(const Ug& s) {  // IsOver :215-222
+  int bw = ug_bwin(s), ww = ug_wwin(s);
+  return (bw > 0 && ww > 0) || bw == 2 || ww == 2;
+}
+
+__device__ inline void ug_clear(Ug& s) {  // ClearBoard :27-48 (black starts on WHITE_BASE and vice versa)
+  s.p[0] = UG_WHITE_BASE; s.p[1] = UG_BLACK_BASE; s.ja = 0; s.meta = 1ull << 8;
+}
+
+// family base indices in the action table: right, left, forward, backward steps (56 each),
+// right, left, forward, backward jumps (48 each), pass
+__host__ __device__ constexpr int ug_base(int g) { return g < 4 ? 56 * g : 224 + 48 * (g - 4); }
+
+// the four jump families of `pieces` over `all2` (occupied squares incl. the square just vacated), :331-352
+__device__ inline void ug_jumps(uint64_t pieces, uint64_t all2, uint64_t fam[8]) {
+  const uint64_t emp2 = ~all2;
+  fam[4] = pieces & (emp2 >> 2) & (all2 >> 1) & UG_NOT_X67;                 // i -> i+2, low = i
+  fam[5] = ((pieces & UG_NOT_X01) >> 2) & emp2 & (all2 >> 1);                // i -> i-2, low = i-2
+  fam[6] = pieces & (emp2 >> 16) & (all2 >> 8);                              // i -> i+16
+  fam[7] = (pieces >> 16) & emp2 & (all2 >> 8);                              // i -> i-16, low = i-16
+}
+
+// get_legal_moves :367-384 as eight bitboards (bit = low square of the pattern) + pass flag
+__device__ inline bool ug_families(const Ug& s, uint64_t fam[8]) {
+  const int a = ug_active(s);
+  const uint64_t all = s.p[0] | s.p[1];
+  if (s.ja != 0) {  // a jump chain is running: only the jumping man, only jumps, or pass (_jumps_from :499-567)
+    const uint64_t pawn = s.p[a] & s.ja;
+    fam[0] = fam[1] = fam[2] = fam[3] = 0;
+    ug_jumps(pawn, all | (s.ja ^ pawn), fam);
+    return (fam[4] | fam[5] | fam[6] | fam[7]) != 0;
+  }
+  // a side must first clear its own starting corner once the opponent has left theirs (:374-383)
+  uint64_t pieces = s.p[a];
+  if (a == 0 && !(s.p[1] & UG_BLACK_BASE) && (s.p[0] & UG_WHITE_BASE)) pieces = s.p[0] & UG_WHITE_BASE;
+  if (a == 1 && !(s.p[0] & UG_WHITE_BASE) && (s.p[1] & UG_BLACK_BASE)) pieces = s.p[1] & UG_BLACK_BASE;
+  const uint64_t empty = ~all;
+  fam[0] = pieces & (empty >> 1) & UG_NOT_X7;                // :313-317
+  fam[1] = ((pieces & UG_NOT_X0) >> 1) & empty;              // :318-322
+  fam[2] = pieces & (empty >> 8);                            // :323-326
+  fam[3] = (pieces >> 8) & empty;                            // :327-330
+  ug_jumps(pieces, all, fam);
+  return false;
+}
+
+__device__ inline uint64_t ug_compress7(uint64_t b) {  // 8 squares/row -> 7 (x < 7)
+  uint64_t r = 0;
+#pragma unroll
+  for (int y = 0; y < 8; ++y) r |= ((b >> (8 * y)) & 0x7Full) << (7 * y);
+  return r;
+}
+__device__ inline uint64_t ug_compress6(uint64_t b) {  // 8 squares/row -> 6 (x < 6)
+  uint64_t r = 0;
+#pragma unroll
+  for (int y = 0; y < 8; ++y) r |= ((b >> (8 * y)) & 0x3Full) << (6 * y);
+  return r;
+}
+
+template <int OFF>
+__device__ inline void ug_put(uint64_t m[7], uint64_t field) {
+  m[OFF >> 6] |= field << (OFF & 63);
+  if ((OFF & 63) != 0 && (OFF >> 6) + 1 < 7) m[(OFF >> 6) + 1] |= field >> (64 - (OFF & 63));
+}
+
+__device__ inline void ug_mask_words(const uint64_t fam[8], bool pass, uint64_t m[7]) {
+#pragma unroll
+  for (int i = 0; i < 7; ++i) m[i] = 0;
+  ug_put<0>(m, ug_compress7(fam[0]));
+  ug_put<56>(m, ug_compress7(fam[1]));
+  ug_put<112>(m, fam[2]);
+  ug_put<168>(m, fam[3]);
+  ug_put<224>(m, ug_compress6(fam[4]));
+  ug_put<272>(m, ug_compress6(fam[5]));
+  ug_put<320>(m, fam[6]);
+  ug_put<368>(m, fam[7]);
+  if (pass) m[6] |= 1ull << (UG_PASS & 63);
+}
+
+__device__ inline int ug_count(const uint64_t fam[8], bool pass) {
+  int c = pass ? 1 : 0;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) c += __popcll(fam[g]);
+  return c;
+}
+
+__device__ inline int ug_action_of(int g, int i) {  // family + low square -> action index
+  int rank = (g < 2) ? i - (i >> 3) : (g == 4 || g == 5) ? i - 2 * (i >> 3) : i;
+  return ug_base(g) + rank;
+}
+__device__ inline void ug_decode(int action, int& g, int& i) {  // action (< 416) -> family + low square
+  g = action < 224 ? action / 56 : 4 + (action - 224) / 48;
+  int r = action - ug_base(g);
+  i = (g < 2) ? r + r / 7 : (g == 4 || g == 5) ? r + 2 * (r / 6) : r;
+}
+
+// Play :51-109.  pass: g = -1
+__device__ inline void ug_play(Ug& s, int g, int i) {
+  int a = ug_active(s), bw = ug_bwin(s), ww = ug_wwin(s);
+  const int ply = ug_ply(s) + 1;
+  uint64_t action = 0;
+  const bool jump = g >= 4;
+  if (g >= 0) {
+    const uint64_t pat = (g < 2) ? 0x3ull : (g < 4) ? 0x101ull : (g < 6) ? 0x5ull : 0x10001ull;
+    action = pat << i;
+  }
+  if (jump) s.ja = action;
+  s.p[0] ^= (a == 0) ? action : 0ull;
+  s.p[1] ^= (a == 1) ? action : 0ull;
+  if ((s.p[0] & UG_BLACK_BASE) == UG_BLACK_BASE) ++bw;           // :85-92 (counted on every Play, pass included)
+  else if ((s.p[1] & UG_WHITE_BASE) == UG_WHITE_BASE) ++ww;
+  else { bw = 0; ww = 0; }
+  bool stay = false;
+  if (jump) {  // the man may go on jumping; the square it came from stays blocked (:95-101)
+    const uint64_t mine = (a == 0) ? s.p[0] : s.p[1];
+    const uint64_t pawn = mine & s.ja;
+    uint64_t fam[8];
+    ug_jumps(pawn, s.p[0] | s.p[1] | (s.ja ^ pawn), fam);
+    stay = (fam[4] | fam[5] | fam[6] | fam[7]) != 0;
+  }
+  if (!stay) { s.ja = 0; a ^= 1; }
+  s.meta = (uint64_t)a | ((uint64_t)(bw & 7) << 1) | ((uint64_t)(ww & 7) << 4) | ((uint64_t)(ply & 0xFFFF) << 8);
+}
+
+__device__ inline void ug_load(const uint64_t* __restrict__ w, int n, int b, Ug& s) {
+  s.p[0] = w[0 * (size_t)n + b]; s.p[1] = w[1 * (size_t)n + b]; s.ja = w[2 * (size_t)n + b]; s.meta = w[3 * (size_t)n + b];
+}
+__device__ inline void ug_store(uint64_t* __restrict__ w, int n, int b, const Ug& s) {
+  w[0 * (size_t)n + b] = s.p[0]; w[1 * (size_t)n + b] = s.p[1]; w[2 * (size_t)n + b] = s.ja; w[3 * (size_t)n + b] = s.meta;
+}
+
+// ---- kernels ------------------------------------------------------------------------------------
+__global__ void ug_reset_kernel(uint64_t* w, int n, const uint8_t* __restrict__ which) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n || (which && !which[b])) return;
+  Ug s; ug_clear(s);
+  ug_store(w, n, b, s);
+}
+
+__global__ void ug_import_kernel(uint64_t* w, const uint64_t* aos, int n) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  Ug s; s.p[0] = aos[b * 4 + 0]; s.p[1] = aos[b * 4 + 1]; s.ja = aos[b * 4 + 2]; s.meta = aos[b * 4 + 3];
+  ug_store(w, n, b, s);
+}
+
+__global__ void ug_export_kernel(const uint64_t* w, uint64_t* aos, int n) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  Ug s; ug_load(w, n, b, s);
+  aos[b * 4 + 0] = s.p[0]; aos[b * 4 + 1] = s.p[1]; aos[b * 4 + 2] = s.ja; aos[b * 4 + 3] = s.meta;
+}
+
+// GetValidMovesBinary :113-129 + terminated() GameState.h:49-51
+__global__ void __launch_bounds__(256)
+ug_mask_kernel(const uint64_t* __restrict__ w, uint64_t* __restrict__ mask, uint8_t* __restrict__ term, int n) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  Ug s; ug_load(w, n, b, s);
+  uint64_t fam[8], m[7];
+  bool pass = ug_families(s, fam);
+  ug_mask_words(fam, pass, m);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) mask[(size_t)b * 7 + i] = m[i];
+  if (term) term[b] = (ug_over(s) || ug_ply(s) >= UG_MAX_PLY) ? 1 : 0;
+}
+
+// GameState::forward GameState.cc:4-18.  TryPlay (:132-213) accepts exactly the members of the legal
+// mask on reachable states (tests/test_oracle_ugolki.py pins that) plus "pass whenever a chain runs".
+__global__ void __launch_bounds__(256)
+ug_step_kernel(uint64_t* __restrict__ w, const int16_t* __restrict__ actions, uint8_t* __restrict__ ok, int n) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  int action = actions[b];
+  bool good = action >= 0 && action <= UG_PASS;
+  if (good) {
+    Ug s; ug_load(w, n, b, s);
+    good = !ug_over(s) && ug_ply(s) < UG_MAX_PLY;
+    if (good) {
+      int g = -1, i = 0;
+      if (action == UG_PASS) good = s.ja != 0;
+      else {
+        uint64_t fam[8];
+        ug_families(s, fam);
+        ug_decode(action, g, i);
+        uint64_t sel = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sel = (q == g) ? fam[q] : sel;
+        good = (sel >> i) & 1;
+      }
+      if (good) { ug_play(s, g, i); ug_store(w, n, b, s); }
+    }
+  }
+  if (ok) ok[b] = good ? 1 : 0;
+}
+
+// evaluateGame GameState.cc:56-70
+__global__ void ug_evaluate_kernel(const uint64_t* __restrict__ w, float* __restrict__ v, int n) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  Ug s; ug_load(w, n, b, s);
+  float r = 0.f;
+  if (ug_ply(s) >= UG_MAX_PLY) r = -1.f;
+  else if (ug_over(s)) r = (ug_bwin(s) > 0 && ug_wwin(s) > 0) ? -1.f : (ug_bwin(s) == 2 ? 1.f : -1.f);
+  v[b] = r;
+}
+
+__global__ void __launch_bounds__(256)
+ug_playout_kernel(uint64_t* __restrict__ w, int n, int nply, uint64_t seed, uint64_t first_id, uint64_t step_base,
+                  unsigned long long* __restrict__ moves_out) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long moves = 0;
+  if (b < n) {
+    Ug s; ug_load(w, n, b, s);
+    const uint64_t key = seed + (first_id + (uint64_t)b) * ELF_GOLDEN + step_base;
+    for (int step = 0; step < nply; ++step) {
+      uint64_t fam[8];
+      bool pass = ug_families(s, fam);
+      int total = ug_count(fam, pass);
+      if (total == 0 || ug_over(s) || ug_ply(s) >= UG_MAX_PLY) { ug_clear(s); continue; }
+      uint64_t r = elf_splitmix64(key + (uint64_t)step);
+      int kk = (int)elf_mod_u64_small(r, (uint32_t)total);
+      // k-th legal move in ascending action index == k-th set bit over fam[0..7], then pass
+      int g = -1; uint64_t sel = 0; bool found = false;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        int c = __popcll(fam[q]);
+        bool here = !found && kk < c;
+        if (here) { g = q; sel = fam[q]; found = true; }
+        if (!found) kk -= c;
+      }
+      int i = 0;
+      if (found) {
+        for (int j = 0; j < kk; ++j) sel &= sel - 1;
+        i = __ffsll((long long)sel) - 1;
+      }
+      ug_play(s, g, i);
+      ++moves;
+    }
+    ug_store(w, n, b, s);
+  }
+  if (moves_out) {
+    for (int o = 32; o > 0; o >>= 1) moves += __shfl_down(moves, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(moves_out, moves);
+  }
+}
+
+// BoardFeature::extract BoardFeature.cc:45-63: plane 0 = the mover's men in the mover's view, plane 1 =
+// the other side's men in THEIR view (white's view is rotated by 180 degrees, GetObservation :229-269),
+// planes 2/3 = black/white to move, planes 4..15 stay zero (NUM_FEATURES = 16).
+template <int DTYPE>
+__global__ void __launch_bounds__(256)
+ug_features_kernel(const uint64_t* __restrict__ w, int n, void* __restrict__ out) {
+  int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  if (b >= n) return;
+  Ug s; ug_load(w, n, b, s);
+  const bool white = ug_active(s) == 1;
+  const bool blk = (s.p[0] >> lane) & 1, wht = (s.p[1] >> (63 - lane)) & 1;
+#pragma unroll
+  for (int q = 0; q < UG_PLANES; ++q) {
+    bool v = q == 0 ? (white ? wht : blk) : q == 1 ? (white ? blk : wht) : q == 2 ? !white : q == 3 ? white : false;
+    if (DTYPE == ELFHIP_F32) ((float*)out)[((size_t)b * UG_PLANES + q) * 64 + lane] = v ? 1.f : 0.f;
+    else if (DTYPE == ELFHIP_BF16) ((uint16_t*)out)[((size_t)b * UG_PLANES + q) * 64 + lane] = v ? 0x3F80 : 0;
+    else {
+      uint64_t bits = __ballot(v);
+      if (lane == 0) ((uint64_t*)out)[(size_t)b * UG_PLANES + q] = bits;
+    }
+  }
+}
+
+struct UgolkiSlab : BoardSlab {
+  uint64_t* w = nullptr;    // [4][n]
+  uint64_t* aos = nullptr;  // [n][4] staging for export/import
+  ~UgolkiSlab() override { (void)hipFree(w); (void)hipFree(aos); }
+  int grid() const { return (n + 255) / 256; }
+  int alloc() override {
+    if (hipMalloc(&w, sizeof(uint64_t) * 4 * (size_t)n) != hipSuccess ||
+        hipMalloc(&aos, sizeof(uint64_t) * 4 * (size_t)n) != hipSuccess) {
+      elfhip_set_error("ugolki: device allocation of %d boards failed", n);
+      return ELFHIP_ENOMEM;
+    }
+    dev_ptr[0] = w;
+    return reset();
+  }
+  int reset() override {
+    step_counter = 0;
+    hipLaunchKernelGGL(ug_reset_kernel, dim3(grid()), dim3(256), 0, stream, w, n, (const uint8_t*)nullptr);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  int reset_mask(const uint8_t* d_which) override {
+    hipLaunchKernelGGL(ug_reset_kernel, dim3(grid()), dim3(256), 0, stream, w, n, d_which);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  int export_states(uint64_t* h) override {
+    hipLaunchKernelGGL(ug_export_kernel, dim3(grid()), dim3(256), 0, stream, w, aos, n);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(h, aos, sizeof(uint64_t) * 4 * (size_t)n, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    return ELFHIP_OK;
+  }
+  int import_states(const uint64_t* h) override {
+    HIPCHECK(hipMemcpyAsync(aos, h, sizeof(uint64_t) * 4 * (size_t)n, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(ug_import_kernel, dim3(grid()), dim3(256), 0, stream, w, aos, n);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(stream));
+    return ELFHIP_OK;
+  }
+  int legal_mask(uint64_t* d_mask, uint8_t* d_terminal) override {
+    hipLaunchKernelGGL(ug_mask_kernel, dim3(grid()), dim3(256), 0, stream, w, d_mask, d_terminal, n);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  int step(const int16_t* d_actions, uint8_t* d_ok) override {
+    hipLaunchKernelGGL(ug_step_kernel, dim3(grid()), dim3(256), 0, stream, w, d_actions, d_ok, n);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  int features(void* d_out, int dtype) override {
+    int blocks = (n + 3) / 4;
+    if (dtype == ELFHIP_F32)
+      hipLaunchKernelGGL(ug_features_kernel<ELFHIP_F32>, dim3(blocks), dim3(256), 0, stream, w, n, d_out);
+    else if (dtype == ELFHIP_BF16)
+      hipLaunchKernelGGL(ug_features_kernel<ELFHIP_BF16>, dim3(blocks), dim3(256), 0, stream, w, n, d_out);
+    else if (dtype == ELFHIP_BITS)
+      hipLaunchKernelGGL(ug_features_kernel<ELFHIP_BITS>, dim3(blocks), dim3(256), 0, stream, w, n, d_out);
+    else { elfhip_set_error("ugolki features: unknown dtype %d", dtype); return ELFHIP_EINVAL; }
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  int evaluate(float* d_value) override {
+    hipLaunchKernelGGL(ug_evaluate_kernel, dim3(grid()), dim3(256), 0, stream, w, d_value, n);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  int playout(int nply, uint64_t seed, uint64_t first_id, unsigned long long* d_moves) override {
+    hipLaunchKernelGGL(ug_playout_kernel, dim3(grid()), dim3(256), 0, stream, w, n, nply, seed, first_id,
+                       step_counter, d_moves);
+    HIPCHECK(hipGetLastError());
+    step_counter += (uint64_t)nply;
+    return ELFHIP_OK;
+  }
+};
+
+}  // namespace
+
+BoardSlab* elfhip_make_ugolki() { return new UgolkiSlab(); }

@@ -38,7 +38,10 @@ enum elfhip_game {
                           black kings as bit y*8+x; word 4 = player(1 white) | has_next<<1 | next_y<<2 |
                           next_x<<5 | ply<<8 | last_move<<24), 6x8x8 planes
                           (reference: russian_checkers/game/CheckersBoard.h:60-90, CheckersFeature.cc:57-82) */
-  ELFHIP_UGOLKI = 2,   /* ugolki           : 418 actions */
+  ELFHIP_UGOLKI = 2,   /* ugolki           : 418 actions (0..415 moves, 416 pass, 417 unused), 4 state words
+                          (pieces[BLACK], pieces[WHITE] as bit y*8+x, jump_action, active | black_win<<1 |
+                          white_win<<4 | ply<<8), 16x8x8 planes of which 0..3 are written
+                          (reference: ugolki/game/GameBoard.h:67-81, BoardFeature.cc:45-63) */
   ELFHIP_GO19 = 3      /* Go 19x19         : 362 actions (361 points + pass), build-defined */
 };
 
