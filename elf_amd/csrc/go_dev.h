@@ -1,0 +1,317 @@
+// Device-side Go 19x19 board code shared by the board slab (go.hip) and the Go tree search
+// (mcts_go.hip).  See go.hip for the formulation notes.
+#pragma once
+#include "common.h"
+
+namespace godev {
+
+constexpr int GN = 19;
+constexpr uint32_t FULL = 0x7FFFFu;
+constexpr int GO_POINTS = 361;
+constexpr int GO_PASS = 361;
+constexpr int GO_MAX_PLY = 722;
+constexpr uint32_t NO_POINT = 0xFFFFu;
+constexpr uint64_t GO_ZSEED = 0x60BA7D5EEDull;
+constexpr int TAB_SLOTS = 1024;
+constexpr int GO_WORDS = 22;
+constexpr int NROWW = 57;  // B[19], W[19], AT[19]
+
+#define ROWS(i) _Pragma("unroll") for (int i = 0; i < GN; ++i)
+#define ROWS_REV(i) _Pragma("unroll") for (int i = GN - 1; i >= 0; --i)
+
+struct GoS {
+  uint32_t P[GN], Q[GN], AT[GN];  // P = stones of the side to move, Q = the other side
+  uint32_t tm, passes, superko, ply, ko, last, capP, capQ;
+  uint64_t hash;
+};
+
+__device__ inline bool go_terminated(const GoS& s) { return s.passes >= 2 || s.ply >= GO_MAX_PLY || s.superko; }
+
+__device__ inline void go_clear(GoS& s) {
+  ROWS(i) { s.P[i] = 0; s.Q[i] = 0; s.AT[i] = 0; }
+  s.tm = 0; s.passes = 0; s.superko = 0; s.ply = 0; s.ko = NO_POINT; s.last = NO_POINT; s.capP = 0; s.capQ = 0;
+  s.hash = 0;
+}
+
+// 4-neighbourhood of a row-bitboard set
+#define NBR(X, i) ((((X)[i] << 1) | ((X)[i] >> 1) | ((i) > 0 ? (X)[(i) > 0 ? (i)-1 : 0] : 0u) | ((i) < GN - 1 ? (X)[(i) < GN - 1 ? (i) + 1 : 0] : 0u)) & FULL)
+
+// Flood fill: grow F (subset of M) to the union of M-connected components it touches.
+// Alternating down/up sweeps, in place; exits when no lane of the wave changed.
+__device__ inline void go_fill(uint32_t (&F)[GN], const uint32_t (&M)[GN]) {
+  // A complete sweep that changes nothing proves a fixpoint, so test after every sweep.
+  for (;;) {
+    uint32_t chg = 0;
+    ROWS(i) {
+      uint32_t up = i > 0 ? F[i > 0 ? i - 1 : 0] : 0u, dn = i < GN - 1 ? F[i < GN - 1 ? i + 1 : 0] : 0u;
+      uint32_t t = (F[i] | up | dn) & M[i];
+      t = (t | (t << 1) | (t >> 1)) & M[i];
+      t = (t | (t << 1) | (t >> 1)) & M[i];
+      chg |= t ^ F[i];
+      F[i] = t;
+    }
+    if (!__any(chg != 0)) break;
+    chg = 0;
+    ROWS_REV(i) {
+      uint32_t up = i > 0 ? F[i > 0 ? i - 1 : 0] : 0u, dn = i < GN - 1 ? F[i < GN - 1 ? i + 1 : 0] : 0u;
+      uint32_t t = (F[i] | up | dn) & M[i];
+      t = (t | (t << 1) | (t >> 1)) & M[i];
+      t = (t | (t << 1) | (t >> 1)) & M[i];
+      chg |= t ^ F[i];
+      F[i] = t;
+    }
+    if (!__any(chg != 0)) break;
+  }
+}
+
+__device__ inline bool go_any_rows(const uint32_t (&X)[GN]) {
+  uint32_t o = 0;
+  ROWS(i) o |= X[i];
+  return __any(o != 0);
+}
+
+// number of liberties of the stone set G (empty points adjacent to it)
+__device__ inline int go_libs(const uint32_t (&G)[GN], const GoS& s) {
+  int n = 0;
+  ROWS(i) {
+    uint32_t e = ~(s.P[i] | s.Q[i]) & FULL;
+    n += __popc(NBR(G, i) & e);
+  }
+  return n;
+}
+
+__device__ inline void go_set_at(GoS& s, const uint32_t (&G)[GN], bool in_atari) {
+  ROWS(i) s.AT[i] = (s.AT[i] & ~G[i]) | (in_atari ? G[i] : 0u);
+}
+
+// whole-board legal point mask for the side to move
+__device__ inline int go_legal_rows(const GoS& s, uint32_t (&L)[GN]) {
+  uint32_t T[GN], E[GN];
+  ROWS(i) {
+    E[i] = ~(s.P[i] | s.Q[i]) & FULL;
+    T[i] = E[i] | (s.P[i] & ~s.AT[i]) | (s.Q[i] & s.AT[i]);
+  }
+  const uint32_t kr = s.ko == NO_POINT ? 99u : s.ko / 19u, kb = s.ko == NO_POINT ? 0u : 1u << (s.ko % 19u);
+  int n = 0;
+  ROWS(i) {
+    uint32_t l = E[i] & NBR(T, i);
+    l &= ~((uint32_t)i == kr ? kb : 0u);
+    L[i] = l;
+    n += __popc(l);
+  }
+  return n;
+}
+
+// Play a stone for the side to move at row r / column bit `bit` (must be legal) when act is true;
+// lanes with act == false run the same instructions with empty seeds and change nothing.
+// Updates stones, AT, hash, ko, capP.  z = Zobrist table in LDS ([colour*361 + point]).
+__device__ inline void go_place(GoS& s, bool act, uint32_t r, uint32_t bit, const uint64_t* z) {
+  if (!act) bit = 0;
+  uint32_t C[GN];  // captured stones
+  uint32_t ncap = 0, cap_pt = 0;
+  uint32_t own_size = 0, own_libs = 0;
+  // jobs: 0 capture (opp groups in atari next to the stone), 1 release (own atari groups next to
+  // captured stones gain liberties), 2 own group of the new stone, 3..6 opp neighbour groups
+#pragma unroll 1
+  for (int job = 0; job < 7; ++job) {
+    uint32_t F[GN];
+    const bool onP = (job == 1 || job == 2);
+    if (job == 0) {
+      ROWS(i) {
+        uint32_t s0 = (uint32_t)i == r ? bit : 0u, su = (uint32_t)i + 1 == r ? bit : 0u, sd = (uint32_t)i == r + 1 ? bit : 0u;
+        F[i] = (((s0 << 1) | (s0 >> 1) | su | sd) & FULL) & s.Q[i] & s.AT[i];
+      }
+    } else if (job == 1) {
+      if (!__any(ncap != 0)) continue;
+      ROWS(i) F[i] = NBR(C, i) & s.P[i] & s.AT[i];
+    } else if (job == 2) {
+      ROWS(i) { uint32_t s0 = (uint32_t)i == r ? bit : 0u; s.P[i] |= s0; F[i] = s0; }
+      if (act) s.hash ^= z[s.tm * GO_POINTS + r * 19 + (__ffs(bit) - 1)];
+    } else {
+      const int d = job - 3;  // 0 up, 1 down, 2 left, 3 right
+      ROWS(i) {
+        uint32_t sd;
+        if (d == 0) sd = (uint32_t)i + 1 == r ? bit : 0u;
+        else if (d == 1) sd = (uint32_t)i == r + 1 ? bit : 0u;
+        else if (d == 2) sd = (uint32_t)i == r ? (bit >> 1) : 0u;
+        else sd = (uint32_t)i == r ? ((bit << 1) & FULL) : 0u;
+        F[i] = sd & s.Q[i];
+      }
+    }
+    if (!go_any_rows(F)) {
+      if (job == 0) { ROWS(i) C[i] = 0; }
+      continue;
+    }
+    if (onP) go_fill(F, s.P); else go_fill(F, s.Q);
+    if (job == 0) {
+      ROWS(i) {
+        C[i] = F[i];
+        s.Q[i] &= ~F[i];
+        s.AT[i] &= ~F[i];
+        ncap += __popc(F[i]);
+        if (F[i]) cap_pt = i * 19 + (__ffs(F[i]) - 1);
+        uint32_t m = F[i];
+        while (__any(m != 0)) {
+          if (m) { int c = __ffs(m) - 1; m &= m - 1; s.hash ^= z[(s.tm ^ 1) * GO_POINTS + i * 19 + c]; }
+        }
+      }
+    } else if (job == 1) {
+      ROWS(i) s.AT[i] &= ~F[i];
+    } else {
+      int libs = go_libs(F, s);
+      go_set_at(s, F, libs == 1);
+      if (job == 2) {
+        own_libs = libs;
+        ROWS(i) own_size += __popc(F[i]);
+      }
+    }
+  }
+  if (act) {
+    s.capP += ncap;
+    s.ko = (ncap == 1 && own_size == 1 && own_libs == 1) ? cap_pt : NO_POINT;
+  }
+}
+
+// positional superko set: returns 1 if h was already present, else inserts it
+__device__ inline uint32_t go_table_test_and_insert(ulonglong2* tab, uint64_t gen, uint64_t h) {
+  uint32_t idx = (uint32_t)(h >> 40) & (TAB_SLOTS - 1);
+  for (int probe = 0; probe < TAB_SLOTS; ++probe) {
+    ulonglong2 e = tab[idx];
+    if (e.y != gen) { tab[idx] = make_ulonglong2(h, gen); return 0; }
+    if (e.x == h) return 1;
+    idx = (idx + 1) & (TAB_SLOTS - 1);
+  }
+  return 0;
+}
+
+// One full forward() for this lane's board: a = point index or GO_PASS; act = lane takes part.
+// The caller has verified legality.  Swaps P/Q so that P is again the side to move.
+// superko(hash) -> 0/1 decides whether the new position repeats an earlier one of this game.
+template <class SK>
+__device__ inline void go_forward_t(GoS& s, bool act, uint32_t a, const uint64_t* z, SK superko) {
+  const bool is_pass = a >= GO_POINTS;
+  const bool pt_move = act && !is_pass;
+  const uint32_t r = pt_move ? a / 19u : 0u, bit = pt_move ? 1u << (a % 19u) : 0u;
+  go_place(s, pt_move, r, bit, z);
+  if (act) {
+    if (is_pass) { s.passes += 1; s.ko = NO_POINT; }
+    else { s.passes = 0; s.superko = superko(s.hash); }
+    s.ply += 1; s.last = a; s.tm ^= 1;
+    ROWS(i) { uint32_t t = s.P[i]; s.P[i] = s.Q[i]; s.Q[i] = t; }
+    uint32_t t = s.capP; s.capP = s.capQ; s.capQ = t;
+  }
+}
+// the board slab's version: the game's own superko table, test and insert
+__device__ inline void go_forward(GoS& s, bool act, uint32_t a, ulonglong2* tab, uint64_t gen, const uint64_t* z) {
+  go_forward_t(s, act, a, z, [&](uint64_t h) { return go_table_test_and_insert(tab, gen, h); });
+}
+
+// ---- SoA storage: rows [57][n] (B, W, AT), meta [4][n], hash [n], gen [n], table [n][1024] -------
+struct GoDev {
+  uint32_t* rows; uint32_t* meta; uint64_t* hash; uint64_t* gen; ulonglong2* table; int n;
+  uint32_t* hist;   // [8 slots][38 rows (19 black, 19 white)][n]: stone snapshots for the 18 planes
+  uint32_t* hmeta;  // [n]: len (1..8) | head << 4   (ring; newest = (head + len - 1) % 8)
+};
+
+// stone history of GoState (8 most recent positions, oracle/go.c push_stones)
+__device__ inline void go_hist_write(const GoDev& d, int b, int slot, const GoS& s) {
+  ROWS(i) {
+    d.hist[((size_t)slot * 38 + i) * d.n + b] = s.tm ? s.Q[i] : s.P[i];
+    d.hist[((size_t)slot * 38 + 19 + i) * d.n + b] = s.tm ? s.P[i] : s.Q[i];
+  }
+}
+__device__ inline void go_hist_set_single(const GoDev& d, int b, const GoS& s) {
+  go_hist_write(d, b, 0, s);
+  d.hmeta[b] = 1u;
+}
+__device__ inline void go_hist_push(const GoDev& d, int b, const GoS& s) {
+  uint32_t m = d.hmeta[b];
+  int len = m & 15, head = (m >> 4) & 7, slot;
+  if (len < 8) { slot = (head + len) & 7; ++len; } else { slot = head; head = (head + 1) & 7; }
+  go_hist_write(d, b, slot, s);
+  d.hmeta[b] = (uint32_t)len | ((uint32_t)head << 4);
+}
+
+__device__ inline void go_load(const GoDev& d, int b, GoS& s) {
+  const size_t n = d.n;
+  uint32_t m0 = d.meta[0 * n + b], m1 = d.meta[1 * n + b];
+  s.tm = m0 & 1; s.passes = (m0 >> 1) & 3; s.superko = (m0 >> 3) & 1; s.ply = m0 >> 16;
+  s.ko = m1 & 0xFFFF; s.last = m1 >> 16;
+  uint32_t cb = d.meta[2 * n + b], cw = d.meta[3 * n + b];
+  s.capP = s.tm ? cw : cb; s.capQ = s.tm ? cb : cw;
+  s.hash = d.hash[b];
+  ROWS(i) {
+    uint32_t bl = d.rows[(size_t)i * n + b], wh = d.rows[(size_t)(19 + i) * n + b];
+    s.P[i] = s.tm ? wh : bl; s.Q[i] = s.tm ? bl : wh;
+    s.AT[i] = d.rows[(size_t)(38 + i) * n + b];
+  }
+}
+
+__device__ inline void go_store(const GoDev& d, int b, const GoS& s) {
+  const size_t n = d.n;
+  d.meta[0 * n + b] = s.tm | (s.passes << 1) | (s.superko << 3) | (s.ply << 16);
+  d.meta[1 * n + b] = (s.ko & 0xFFFF) | (s.last << 16);
+  d.meta[2 * n + b] = s.tm ? s.capQ : s.capP;
+  d.meta[3 * n + b] = s.tm ? s.capP : s.capQ;
+  d.hash[b] = s.hash;
+  ROWS(i) {
+    d.rows[(size_t)i * n + b] = s.tm ? s.Q[i] : s.P[i];
+    d.rows[(size_t)(19 + i) * n + b] = s.tm ? s.P[i] : s.Q[i];
+    d.rows[(size_t)(38 + i) * n + b] = s.AT[i];
+  }
+}
+
+__device__ inline void go_load_zobrist(uint64_t* z, const uint64_t* gz) {
+  for (int i = threadIdx.x; i < 2 * GO_POINTS; i += blockDim.x) z[i] = gz[i];
+  __syncthreads();
+}
+
+// AT from scratch (import): label every group of both colours
+__device__ inline void go_recompute_at(GoS& s) {
+  ROWS(i) s.AT[i] = 0;
+#pragma unroll 1
+  for (int col = 0; col < 2; ++col) {
+    uint32_t rem[GN];
+    ROWS(i) rem[i] = col ? s.Q[i] : s.P[i];
+    while (go_any_rows(rem)) {
+      uint32_t F[GN];
+      bool found = false;
+      ROWS(i) {
+        uint32_t lb = rem[i] & (0u - rem[i]);
+        F[i] = found ? 0u : lb;
+        found = found || rem[i] != 0;
+      }
+      if (col) go_fill(F, s.Q); else go_fill(F, s.P);
+      int libs = go_libs(F, s);
+      ROWS(i) { s.AT[i] |= (libs == 1) ? F[i] : 0u; rem[i] &= ~F[i]; }
+    }
+  }
+}
+
+// rows -> 362-bit action mask (bit r*19+c; bit 361 = pass)
+__device__ inline void go_pack_mask(const uint32_t (&L)[GN], bool alive, uint64_t (&m)[6]) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) m[k] = 0;
+  ROWS(i) {
+    const int base = i * 19, w = base >> 6, o = base & 63;
+    uint64_t v = alive ? (uint64_t)L[i] : 0ull;
+    m[w] |= v << o;
+    if (o + 19 > 64) m[w + 1] |= v >> (64 - o);
+  }
+  if (alive) m[GO_PASS >> 6] |= 1ull << (GO_PASS & 63);
+}
+
+
+// read-only membership test of the positional-superko set (tree search: a node must not insert)
+__device__ inline uint32_t go_table_contains(const ulonglong2* tab, uint64_t gen, uint64_t h) {
+  uint32_t idx = (uint32_t)(h >> 40) & (TAB_SLOTS - 1);
+  for (int probe = 0; probe < TAB_SLOTS; ++probe) {
+    ulonglong2 e = tab[idx];
+    if (e.y != gen) return 0;
+    if (e.x == h) return 1;
+    idx = (idx + 1) & (TAB_SLOTS - 1);
+  }
+  return 0;
+}
+
+}  // namespace godev

@@ -1,0 +1,481 @@
+// Game-independent part of the batched PUCT tree search (see mcts.hip for the design notes):
+// tree storage, the descent (findMove / UCT / addVirtualLoss / followEdge), pi2response +
+// setEvaluation, the batch backup, chooseAction / result reporting, move picking and treeAdvance.
+// The games plug in through a small static interface (mcts.hip: American checkers, state created
+// while descending; mcts_go.hip: Go, state created afterwards by a lane-per-leaf kernel).
+//
+// Reference: elf/ai/tree_search/tree_search.h:241-378, tree_search_node.h:188-317,385-421,458-507,
+// tree_search_base.h:175-201,310-367, elfgames/american_checkers/mcts/MCTSGameActor.h:198-335.
+#pragma once
+#include <cmath>
+#include <new>
+#include <vector>
+#include "common.h"
+#include "stdorder.h"
+
+namespace mcts {
+
+constexpr int MAXD = 256;  // longest trajectory
+constexpr int MAXB = 16;   // num_rollouts_per_batch limit
+enum { NOT_VISITED = 0, EVAL_REQUESTED = 1, VISITED = 2 };
+// node meta: status (bits 0..7) | flip << 8 | state_set << 9 | n_edges << 16
+constexpr uint32_t META_STATE_SET = 1u << 9, META_FLIP = 1u << 8;
+enum { FLAG_NODE_OVERFLOW = 1, FLAG_EDGE_OVERFLOW = 2, FLAG_DEPTH_OVERFLOW = 4, FLAG_LEGAL_OVERFLOW = 8, FLAG_ROOT_MISMATCH = 16 };
+
+struct Opt {
+  int R, B, vl, use_prior; float c_puct; int uqz, ruqz, persistent, pick;
+};
+
+struct TreeDev {
+  int n_trees, max_nodes, max_edges, state_words;  // state_words: u32 words of game state per node
+  // nodes [2][n_trees][max_nodes]
+  uint32_t* n_meta; uint32_t* n_ebase; int32_t* n_visits; float* n_V; float* n_meanQ; float* n_parentQ;
+  int32_t* n_parent; uint16_t* n_paction; uint32_t* n_state;
+  // edges [2][n_trees][max_edges]
+  uint16_t* e_action; float* e_prior; int32_t* e_child; float* e_reward; int32_t* e_visits; float* e_vloss;
+  // per tree
+  int32_t* t_arena; int32_t* t_nnodes; int32_t* t_nedges; int32_t* t_flags;
+  // batch scratch
+  uint16_t* traj_node; uint16_t* traj_edge;  // [n_trees][B][MAXD]
+  int32_t* traj_len; int32_t* leaf; uint8_t* locked;  // [n_trees][B]
+  const uint16_t* uniform_order;  // std::sort order of num_actions equal keys
+  unsigned long long* stats;      // rollouts, evals, depth_sum, edge_sum
+};
+
+struct TV {  // one tree, one arena
+  uint32_t* meta; uint32_t* ebase; int32_t* visits; float* V; float* meanQ; float* parentQ; int32_t* parent;
+  uint16_t* paction; uint32_t* state;
+  uint16_t* ea; float* ep; int32_t* ec; float* er; int32_t* ev; float* el;
+};
+
+__device__ inline TV tree_view(const TreeDev& d, int t, int arena) {
+  size_t nb = ((size_t)arena * d.n_trees + t) * d.max_nodes, eb = ((size_t)arena * d.n_trees + t) * d.max_edges;
+  TV v;
+  v.meta = d.n_meta + nb; v.ebase = d.n_ebase + nb; v.visits = d.n_visits + nb; v.V = d.n_V + nb;
+  v.meanQ = d.n_meanQ + nb; v.parentQ = d.n_parentQ + nb; v.parent = d.n_parent + nb; v.paction = d.n_paction + nb;
+  v.state = d.n_state + nb * d.state_words;
+  v.ea = d.e_action + eb; v.ep = d.e_prior + eb; v.ec = d.e_child + eb; v.er = d.e_reward + eb;
+  v.ev = d.e_visits + eb; v.el = d.e_vloss + eb;
+  return v;
+}
+
+__device__ inline void init_node(TV& tv, int id, float pq, int parent, int paction) {  // NodeT ctor tree_search_node.h:110-115
+  tv.meta[id] = NOT_VISITED; tv.ebase[id] = 0; tv.visits[id] = 0; tv.V[id] = 0.f;
+  tv.meanQ[id] = pq; tv.parentQ[id] = pq; tv.parent[id] = parent; tv.paction[id] = (uint16_t)paction;
+}
+
+// One descent from the root (single_rollout tree_search.h:319-378).  Wave-uniform; returns the leaf.
+// All lanes perform the scalar stores redundantly (same value, same address) so that each lane's
+// later loads are ordered after its own stores.
+// Game::on_new_child(d, tv, parent, child, action): allocateState (tree_search.h:209-224) - either
+// play the move now (checkers) or leave the child's state pending for a later kernel (Go).
+template <class Game>
+__device__ inline int select_one(const TreeDev& d, TV& tv, const Opt& o, int t, int slot, int lane, int& nn, int& flags,
+                                 int& depth_out) {
+  uint16_t* tn = d.traj_node + ((size_t)t * o.B + slot) * MAXD;
+  uint16_t* te = d.traj_edge + ((size_t)t * o.B + slot) * MAXD;
+  int node = 0, depth = 0;
+  for (;;) {
+    const uint32_t meta = tv.meta[node];
+    if ((meta & 0xFF) != VISITED) break;
+    const int ne = (int)(meta >> 16);
+    if (ne == 0) break;  // findMove: no edges (terminal position)
+    if (depth >= MAXD) { flags |= FLAG_DEPTH_OVERFLOW; break; }
+    const bool flip = (meta & META_FLIP) != 0;
+    const int eb = (int)tv.ebase[node];
+    float mq = tv.meanQ[node];
+    if (o.uqz || (o.ruqz && depth == 0)) mq = 0.0f;
+    const float pq = tv.parentQ[node];
+    const int nv = tv.visits[node];
+    const double sq = sqrt((double)(nv + 1));
+    float best = -INFINITY; int bestj = 0x7FFFFFFF;
+    float total_uq = 0.f; int total_cnt = 0;
+    for (int base = 0; base < ne; base += 64) {
+      const int j = base + lane;
+      const bool ok = j < ne;
+      float score = -INFINITY, uq = 0.f; int counted = 0;
+      if (ok) {  // EdgeInfo::getScore tree_search_base.h:175-201
+        const float prior = tv.ep[eb + j], reward = tv.er[eb + j], vloss = tv.el[eb + j];
+        const int visits = tv.ev[eb + j];
+        float r = flip ? -reward : reward;
+        r -= vloss;
+        const int nvl = (int)((float)visits + vloss);
+        const float q = nvl > 0 ? r / (float)nvl : (flip ? -mq : mq);
+        uq = visits > 0 ? reward / (float)visits : mq;
+        const float u = (float)((double)(prior / (float)(1 + visits)) * sq);
+        score = o.use_prior ? (u * o.c_puct + q) : q;
+        counted = nvl != 0;
+      }
+      // first strict maximum in edge order == max score, lowest index on ties
+      float s = score; int sj = ok ? j : 0x7FFFFFFF;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        float s2 = __shfl_xor(s, off); int j2 = __shfl_xor(sj, off);
+        if (s2 > s || (s2 == s && j2 < sj)) { s = s2; sj = j2; }
+      }
+      if (s > best || (s == best && sj < bestj)) { best = s; bestj = sj; }
+      // total_unsigned_q is a float sum in edge order: keep the order (only counted edges add)
+      unsigned long long cm = __ballot(counted != 0);
+      while (cm) {
+        const int k = __ffsll((long long)cm) - 1;
+        cm &= cm - 1;
+        total_uq += __shfl(uq, k); total_cnt++;
+      }
+    }
+    mq = (pq + total_uq) / (float)(total_cnt + 1);  // tree_search_node.h:240-241
+    tv.meanQ[node] = mq;
+    const int e = eb + bestj;
+    if (o.vl > 0) tv.el[e] = tv.el[e] + (float)o.vl;  // addVirtualLoss :246-264
+    tn[depth] = (uint16_t)node; te[depth] = (uint16_t)bestj;
+    int child = tv.ec[e];
+    if (child < 0) {  // followEdge :295-317 + allocateState tree_search.h:209-224
+      if (nn >= d.max_nodes) { flags |= FLAG_NODE_OVERFLOW; ++depth; break; }
+      child = nn++;
+      const int action = tv.ea[e];
+      init_node(tv, child, mq, node, action);
+      Game::on_new_child(d, tv, node, child, action);
+      tv.ec[e] = child;
+    }
+    __threadfence_block();
+    node = child;
+    ++depth;
+  }
+  d.traj_len[(size_t)t * o.B + slot] = depth;
+  depth_out = depth;
+  return node;
+}
+
+template <int NA, int MAXLEGAL>
+struct ExpandScratch {
+  stdorder::Item items[NA + 2];
+  uint16_t keys[MAXLEGAL]; float pri[MAXLEGAL]; int16_t nxt[MAXLEGAL]; int16_t buckets[MAXLEGAL <= 64 ? 128 : 544];
+  uint16_t pos[MAXLEGAL];
+  int m;
+};
+
+// setEvaluation (tree_search_node.h:188-215) of a locked leaf from the actor's response
+// (MCTSGameActor.h:198-335): pi2response = std::sort all (action, pi) pairs descending, keep the legal
+// ones, normalise; the edges are then stored in std::unordered_map iteration order.
+// pi == nullptr selects the uniform evaluator (pi = 1/NA).  mk = legal mask words of the leaf.
+template <int NA, int MAXLEGAL>
+__device__ inline void expand_edges(const TreeDev& d, TV& tv, int leaf, bool terminal, bool flip, float value,
+                                    const uint64_t* mk, const float* __restrict__ pi, int lane, int& ne_cnt, int& flags,
+                                    ExpandScratch<NA, MAXLEGAL>& S, unsigned long long& evals, unsigned long long& edge_sum) {
+  int m = 0;
+  const int eb = ne_cnt;
+  if (!terminal) {
+    evals += 1;
+    if (pi) {
+      for (int i = lane; i < NA; i += 64) { S.items[i].key = pi[i]; S.items[i].idx = (uint16_t)i; }
+    } else {
+      for (int i = lane; i < NA; i += 64) { S.items[i].key = 1.0f / (float)NA; S.items[i].idx = d.uniform_order[i]; }
+    }
+    __syncthreads();
+    if (lane == 0) {
+      if (pi) stdorder::sort_desc(S.items, NA);              // std::sort, MCTSGameActor.h:295-300
+      int mm = 0; bool over = false;
+      for (int i = 0; i < NA; ++i) {                          // checkMove filter :305-331
+        const int a = S.items[i].idx;
+        if ((mk[a >> 6] >> (a & 63)) & 1) {
+          if (mm < MAXLEGAL) { S.keys[mm] = (uint16_t)a; S.pri[mm] = S.items[i].key; ++mm; } else over = true;
+        }
+      }
+      float tot = 1e-10f;                                     // normalize :240-251
+      for (int k = 0; k < mm; ++k) tot += S.pri[k];
+      for (int k = 0; k < mm; ++k) S.pri[k] /= tot;
+      stdorder::umap_iteration_order(S.keys, mm, S.nxt, S.buckets, S.pos);
+      S.m = over ? -1 : mm;
+    }
+    __syncthreads();
+    m = S.m;
+    if (m < 0) { flags |= FLAG_LEGAL_OVERFLOW; m = 0; }
+    if (eb + m > d.max_edges) { flags |= FLAG_EDGE_OVERFLOW; m = 0; }
+    for (int j = lane; j < m; j += 64) {
+      const int p = S.pos[j];
+      tv.ea[eb + j] = S.keys[p]; tv.ep[eb + j] = S.pri[p];
+      tv.ec[eb + j] = -1; tv.er[eb + j] = 0.f; tv.ev[eb + j] = 0; tv.el[eb + j] = 0.f;
+    }
+    __syncthreads();
+    ne_cnt += m;
+    edge_sum += (unsigned long long)m;
+  }
+  tv.V[leaf] = value;
+  tv.ebase[leaf] = (uint32_t)eb;
+  tv.meta[leaf] = VISITED | (flip ? META_FLIP : 0u) | META_STATE_SET | ((uint32_t)m << 16);
+  __threadfence_block();
+}
+
+// backup of one batch (tree_search.h:291-305 + updateEdgeStats tree_search_node.h:267-292):
+// per DISTINCT leaf, along the first trajectory that reached it; duplicates only raise `count`.
+__device__ inline void backup_batch(const TreeDev& d, TV& tv, const Opt& o, int t, const int* leafs) {
+  for (int j = 0; j < o.B; ++j) {
+    const int leaf = leafs[j];
+    bool first = true; int count = 0;
+    for (int k = 0; k < o.B; ++k) if (leafs[k] == leaf) { if (k < j) first = false; ++count; }
+    if (!first) continue;
+    const float reward = tv.V[leaf];
+    const int len = d.traj_len[(size_t)t * o.B + j];
+    const uint16_t* tn = d.traj_node + ((size_t)t * o.B + j) * MAXD;
+    const uint16_t* te = d.traj_edge + ((size_t)t * o.B + j) * MAXD;
+    for (int i = 0; i < len; ++i) {
+      const int node = tn[i];
+      const int e = (int)tv.ebase[node] + te[i];
+      tv.visits[node] = tv.visits[node] + 1;
+      tv.er[e] = tv.er[e] + reward;
+      tv.ev[e] = tv.ev[e] + 1;
+      tv.el[e] = tv.el[e] - (float)(o.vl * count);
+    }
+  }
+  __threadfence_block();
+}
+
+// ---- kernels (grid = n_trees blocks of one wave) ------------------------------------------------
+
+static __global__ void __launch_bounds__(64) mcts_clear_kernel(TreeDev d, const uint8_t* __restrict__ which) {
+  const int t = blockIdx.x;
+  if (which && !which[t]) return;
+  TV tv = tree_view(d, t, 0);
+  if (threadIdx.x == 0) {
+    init_node(tv, 0, 0.f, -1, 0);
+    d.t_arena[t] = 0; d.t_nnodes[t] = 1; d.t_nedges[t] = 0; d.t_flags[t] = 0;
+  }
+}
+
+// chooseAction + MCTSResultT::addActions (tree_search.h:588-621, tree_search_base.h:310-367) and
+// MCTSGameAI::getValue (MCTSGameAI.h:40-46).  Edges are reported in iteration order.
+static __global__ void __launch_bounds__(64)
+mcts_result_kernel(TreeDev d, int NA, int pick, int16_t* __restrict__ best_out, int32_t* __restrict__ total_out,
+                   float* __restrict__ bestq_out, float* __restrict__ rootv_out, int32_t* __restrict__ nedges_out,
+                   int16_t* __restrict__ ea_out, int32_t* __restrict__ ev_out, float* __restrict__ er_out,
+                   float* __restrict__ ep_out, int cap, int32_t* __restrict__ policy_out) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  TV tv = tree_view(d, t, d.t_arena[t]);
+  const uint32_t meta = tv.meta[0];
+  const int ne = (meta & 0xFF) == VISITED ? (int)(meta >> 16) : 0;
+  const int eb = (int)tv.ebase[0];
+  float best = -INFINITY; int bestj = 0x7FFFFFFF; int total = 0;
+  if (policy_out) for (int a = lane; a < NA; a += 64) policy_out[(size_t)t * NA + a] = 0;
+  __syncthreads();
+  for (int base = 0; base < ne; base += 64) {
+    const int j = base + lane; const bool ok = j < ne;
+    int visits = 0; float score = -INFINITY;
+    if (ok) {
+      visits = tv.ev[eb + j];
+      score = pick == 0 ? (float)visits : tv.ep[eb + j];
+      if (j < cap) {
+        if (ea_out) ea_out[(size_t)t * cap + j] = (int16_t)tv.ea[eb + j];
+        if (ev_out) ev_out[(size_t)t * cap + j] = visits;
+        if (er_out) er_out[(size_t)t * cap + j] = tv.er[eb + j];
+        if (ep_out) ep_out[(size_t)t * cap + j] = tv.ep[eb + j];
+      }
+      if (policy_out) policy_out[(size_t)t * NA + tv.ea[eb + j]] = visits;
+    }
+    float s = score; int sj = ok ? j : 0x7FFFFFFF; int tv_sum = visits;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      float s2 = __shfl_xor(s, off); int j2 = __shfl_xor(sj, off);
+      if (s2 > s || (s2 == s && j2 < sj)) { s = s2; sj = j2; }
+      tv_sum += __shfl_xor(tv_sum, off);
+    }
+    if (s > best || (s == best && sj < bestj)) { best = s; bestj = sj; }
+    total += tv_sum;
+  }
+  if (lane == 0) {
+    const float rootv = tv.V[0];
+    if (ne == 0) {
+      if (best_out) best_out[t] = -1;
+      if (bestq_out) bestq_out[t] = rootv;
+    } else {
+      if (best_out) best_out[t] = (int16_t)tv.ea[eb + bestj];
+      if (bestq_out) bestq_out[t] = total == 0 ? rootv : tv.er[eb + bestj] / (float)tv.ev[eb + bestj];
+    }
+    if (total_out) total_out[t] = total;
+    if (rootv_out) rootv_out[t] = rootv;
+    if (nedges_out) nedges_out[t] = ne;
+  }
+}
+
+// mcts_make_diverse_move / mcts_update_info (ClientGameSelfPlay.cc:94-122) + addMCTSPolicy
+// (GameStateExt.h:79-100) + MCTSPolicy::normalize (tree_search_base.h:251-262)
+static __global__ void __launch_bounds__(64)
+mcts_pick_kernel(TreeDev d, int NA, const int32_t* __restrict__ ply, int cutoff, uint64_t seed, uint64_t counter,
+                 int16_t* __restrict__ move, uint8_t* __restrict__ pol, float* __restrict__ value) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  TV tv = tree_view(d, t, d.t_arena[t]);
+  const uint32_t meta = tv.meta[0];
+  const int ne = (meta & 0xFF) == VISITED ? (int)(meta >> 16) : 0;
+  const int eb = (int)tv.ebase[0];
+  if (pol) for (int a = lane; a < NA; a += 64) pol[(size_t)t * NA + a] = 0;
+  __syncthreads();
+  // pass 1: totals, most-visited edge (first strict max in edge order)
+  int total = 0, bestv = -1, bestj = 0x7FFFFFFF;
+  for (int base = 0; base < ne; base += 64) {
+    const int j = base + lane;
+    int v = j < ne ? tv.ev[eb + j] : -1, vj = j < ne ? j : 0x7FFFFFFF, sum = j < ne ? v : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      int v2 = __shfl_xor(v, off), j2 = __shfl_xor(vj, off);
+      if (v2 > v || (v2 == v && j2 < vj)) { v = v2; vj = j2; }
+      sum += __shfl_xor(sum, off);
+    }
+    if (v > bestv || (v == bestv && vj < bestj)) { bestv = v; bestj = vj; }
+    total += sum;
+  }
+  const bool diverse = ply && ply[t] <= cutoff && total > 0;
+  const uint64_t r = diverse ? elf_splitmix64(seed + (uint64_t)t * ELF_GOLDEN + counter) % (uint64_t)total : 0;
+  const float exp_sum = (float)total, maxp = total > 0 ? (float)bestv / exp_sum : 0.f;
+  int chosen = ne > 0 ? bestj : -1, cum = 0;
+  bool picked = false;
+  for (int base = 0; base < ne; base += 64) {
+    const int j = base + lane;
+    const int v = j < ne ? tv.ev[eb + j] : 0;
+    if (pol && j < ne) {
+      const float p = (float)v / exp_sum;
+      const float q = p / maxp * 255.0f;
+      pol[(size_t)t * NA + tv.ea[eb + j]] = total > 0 ? (uint8_t)q : 0;
+    }
+    if (diverse && !picked) {
+      int incl = v;  // inclusive prefix sum over the wave
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { int x = __shfl_up(incl, off); if (lane >= off) incl += x; }
+      const unsigned long long hit = __ballot(j < ne && (uint64_t)(cum + incl) > r);
+      if (hit) { chosen = base + (__ffsll((long long)hit) - 1); picked = true; }
+      cum += __shfl(incl, 63);
+    }
+  }
+  if (lane == 0) {
+    move[t] = chosen < 0 ? (int16_t)-1 : (int16_t)tv.ea[eb + chosen];
+    if (value) value[t] = (ne == 0 || total == 0) ? tv.V[0] : tv.er[eb + bestj] / (float)tv.ev[eb + bestj];
+  }
+}
+
+// TreeT::treeAdvance tree_search_node.h:458-474: keep the chosen child's subtree, drop the rest.
+// The kept subtree is copied breadth-first into the other arena (new indices, same contents).
+static __global__ void __launch_bounds__(64) mcts_advance_kernel(TreeDev d, const int16_t* __restrict__ actions) {
+  extern __shared__ uint16_t s_map[];  // new index -> old index  [max_nodes]
+  __shared__ int s_child;
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int a = actions[t];
+  if (a < 0) return;
+  const int arena = d.t_arena[t];
+  const int sw = d.state_words;
+  TV o = tree_view(d, t, arena), n = tree_view(d, t, arena ^ 1);
+  const uint32_t meta = o.meta[0];
+  const int ne0 = (meta & 0xFF) == VISITED ? (int)(meta >> 16) : 0;
+  const int eb0 = (int)o.ebase[0];
+  if (lane == 0) s_child = -1;
+  __syncthreads();
+  for (int j = lane; j < ne0; j += 64) if (o.ea[eb0 + j] == (uint16_t)a) s_child = o.ec[eb0 + j];
+  __syncthreads();
+  const int c = s_child;
+  if (c < 0) {  // never expanded: fresh root (allocateRoot -> addNode(0.0))
+    if (lane == 0) { init_node(n, 0, 0.f, -1, 0); d.t_arena[t] = arena ^ 1; d.t_nnodes[t] = 1; d.t_nedges[t] = 0; }
+    return;
+  }
+  auto copy_node = [&](int dst, int src, int parent) {
+    n.meta[dst] = o.meta[src]; n.visits[dst] = o.visits[src]; n.V[dst] = o.V[src];
+    n.meanQ[dst] = o.meanQ[src]; n.parentQ[dst] = o.parentQ[src]; n.parent[dst] = parent; n.paction[dst] = o.paction[src];
+    for (int k = 0; k < sw; ++k) n.state[(size_t)dst * sw + k] = o.state[(size_t)src * sw + k];
+  };
+  if (lane == 0) { copy_node(0, c, -1); s_map[0] = (uint16_t)c; }
+  __syncthreads();
+  int count = 1, ecount = 0;
+  for (int i = 0; i < count; ++i) {
+    const int old = s_map[i];
+    const uint32_t m = o.meta[old];
+    const int ne = (m & 0xFF) == VISITED ? (int)(m >> 16) : 0;
+    const int eb = (int)o.ebase[old];
+    if (lane == 0) n.ebase[i] = (uint32_t)ecount;
+    for (int base = 0; base < ne; base += 64) {
+      const int j = base + lane; const bool ok = j < ne;
+      int oc = -1;
+      if (ok) {
+        oc = o.ec[eb + j];
+        n.ea[ecount + j] = o.ea[eb + j]; n.ep[ecount + j] = o.ep[eb + j]; n.er[ecount + j] = o.er[eb + j];
+        n.ev[ecount + j] = o.ev[eb + j]; n.el[ecount + j] = o.el[eb + j];
+      }
+      const unsigned long long has = __ballot(ok && oc >= 0);
+      if (ok) {
+        int ni = -1;
+        if (oc >= 0) {
+          ni = count + __popcll(has & ((1ull << lane) - 1));
+          s_map[ni] = (uint16_t)oc;
+          copy_node(ni, oc, i);
+        }
+        n.ec[ecount + j] = ni;
+      }
+      count += __popcll(has);
+    }
+    ecount += ne;
+    __syncthreads();
+  }
+  if (lane == 0) { d.t_arena[t] = arena ^ 1; d.t_nnodes[t] = count; d.t_nedges[t] = ecount; }
+}
+
+#define MCTS_ALLOC(ptr, bytes)                                                                  \
+  do {                                                                                          \
+    if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) {                                     \
+      elfhip_set_error("mcts: device allocation of %zu bytes failed", (size_t)(bytes));          \
+      return ELFHIP_ENOMEM;                                                                     \
+    }                                                                                           \
+    allocs.push_back((void*)(ptr));                                                             \
+  } while (0)
+
+// Host side shared by the games.  One object per elfhip_mcts handle.
+struct MctsBase {
+  TreeDev d{};
+  Opt o{};
+  int game = 0, device = 0, num_actions = 0;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  uint16_t* uniform_order = nullptr;
+  virtual ~MctsBase() { for (void* p : allocs) (void)hipFree(p); }
+
+  // game specific
+  virtual int set_roots(BoardSlab* slab, uint8_t* d_ok) = 0;
+  virtual int run_uniform() = 0;
+  virtual int select(uint64_t* d_leaf_states, float* d_leaf_features, uint8_t* d_need_eval) = 0;
+  virtual int backup(const float* d_pi, const float* d_value) = 0;
+
+  int alloc_common(int n_trees, const elfhip_ts_options* opt, int na, int state_words, int default_edges_per_node) {
+    num_actions = na;
+    o.R = opt->num_rollouts_per_thread; o.B = opt->num_rollouts_per_batch; o.vl = opt->virtual_loss;
+    o.use_prior = opt->use_prior; o.c_puct = opt->c_puct; o.uqz = opt->unexplored_q_zero;
+    o.ruqz = opt->root_unexplored_q_zero; o.persistent = opt->persistent_tree; o.pick = opt->pick_method;
+    d.n_trees = n_trees; d.state_words = state_words;
+    d.max_nodes = opt->max_nodes > 0 ? opt->max_nodes : 8 * o.R + 64;
+    if (d.max_nodes > 30000) d.max_nodes = 30000;  // u16 node ids; the advance kernel maps them in LDS
+    d.max_edges = opt->max_edges > 0 ? opt->max_edges : default_edges_per_node * d.max_nodes;
+    const size_t NN = (size_t)2 * n_trees * d.max_nodes, NE = (size_t)2 * n_trees * d.max_edges, T = (size_t)n_trees;
+    MCTS_ALLOC(d.n_meta, NN * 4); MCTS_ALLOC(d.n_ebase, NN * 4); MCTS_ALLOC(d.n_visits, NN * 4); MCTS_ALLOC(d.n_V, NN * 4);
+    MCTS_ALLOC(d.n_meanQ, NN * 4); MCTS_ALLOC(d.n_parentQ, NN * 4); MCTS_ALLOC(d.n_parent, NN * 4);
+    MCTS_ALLOC(d.n_paction, NN * 2); MCTS_ALLOC(d.n_state, NN * 4 * (size_t)state_words);
+    MCTS_ALLOC(d.e_action, NE * 2); MCTS_ALLOC(d.e_prior, NE * 4); MCTS_ALLOC(d.e_child, NE * 4); MCTS_ALLOC(d.e_reward, NE * 4);
+    MCTS_ALLOC(d.e_visits, NE * 4); MCTS_ALLOC(d.e_vloss, NE * 4);
+    MCTS_ALLOC(d.t_arena, T * 4); MCTS_ALLOC(d.t_nnodes, T * 4); MCTS_ALLOC(d.t_nedges, T * 4); MCTS_ALLOC(d.t_flags, T * 4);
+    MCTS_ALLOC(d.traj_node, T * o.B * MAXD * 2); MCTS_ALLOC(d.traj_edge, T * o.B * MAXD * 2);
+    MCTS_ALLOC(d.traj_len, T * o.B * 4); MCTS_ALLOC(d.leaf, T * o.B * 4); MCTS_ALLOC(d.locked, T * o.B);
+    MCTS_ALLOC(uniform_order, (size_t)na * 2); MCTS_ALLOC(d.stats, 4 * 8);
+    d.uniform_order = uniform_order;
+    // std::sort order of `na` equal keys, computed once with the same code the kernels run
+    std::vector<stdorder::Item> it((size_t)na);
+    for (int i = 0; i < na; ++i) { it[i].key = 1.0f / (float)na; it[i].idx = (uint16_t)i; }
+    stdorder::sort_desc(it.data(), na);
+    std::vector<uint16_t> ord((size_t)na);
+    for (int i = 0; i < na; ++i) ord[i] = it[i].idx;
+    HIPCHECK(hipMemcpy(uniform_order, ord.data(), (size_t)na * 2, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemsetAsync(d.stats, 0, 32, stream));
+    HIPCHECK(hipMemsetAsync(d.t_flags, 0, T * 4, stream));
+    return clear(nullptr);
+  }
+  int clear(const uint8_t* d_which) {
+    hipLaunchKernelGGL(mcts_clear_kernel, dim3(d.n_trees), dim3(64), 0, stream, d, d_which);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+};
+
+}  // namespace mcts
+
+mcts::MctsBase* elfhip_make_mcts_american(int n_trees, const elfhip_ts_options* opt, int* rc);
+mcts::MctsBase* elfhip_make_mcts_go(int n_trees, const elfhip_ts_options* opt, int* rc);

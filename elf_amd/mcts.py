@@ -54,8 +54,9 @@ class TreeSearchBatch:
         check(self.L.elfhip_mcts_run_uniform(self.h))
 
     def select(self, want_states=True, want_features=False):
-        st = torch.empty((self.n, self.B, 6), dtype=torch.int64, device=self.device) if want_states else None
-        ft = torch.empty((self.n, self.B, self.info.num_planes, 8, 8), dtype=torch.float32, device=self.device) if want_features else None
+        bs = self.info.board_size
+        st = torch.empty((self.n, self.B, self.info.state_words), dtype=torch.int64, device=self.device) if want_states else None
+        ft = torch.empty((self.n, self.B, self.info.num_planes, bs, bs), dtype=torch.float32, device=self.device) if want_features else None
         ne = torch.empty((self.n, self.B), dtype=torch.uint8, device=self.device)
         check(self.L.elfhip_mcts_select(self.h, st.data_ptr() if st is not None else None,
                                         ft.data_ptr() if ft is not None else None, ne.data_ptr()))
@@ -67,10 +68,11 @@ class TreeSearchBatch:
         check(self.L.elfhip_mcts_backup(self.h, pi.data_ptr(), value.data_ptr()))
 
     def run(self, evaluator):
-        """TreeSearchT::run with an external evaluator: evaluator(features[n*B,planes,8,8], states) -> (pi, V)"""
+        """TreeSearchT::run with an external evaluator: evaluator(features[n*B,planes,size,size], states, need) -> (pi, V)"""
+        bs = self.info.board_size
         for _ in range((self.R + self.B - 1) // self.B):
             st, ft, ne = self.select(want_states=True, want_features=True)
-            pi, v = evaluator(ft.view(self.n * self.B, self.info.num_planes, 8, 8), st, ne)
+            pi, v = evaluator(ft.view(self.n * self.B, self.info.num_planes, bs, bs), st, ne)
             self.backup(pi.contiguous(), v.contiguous())
 
     def result(self, edge_cap=64, with_policy=False):

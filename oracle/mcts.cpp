@@ -1,5 +1,6 @@
-// TEST INFRASTRUCTURE ONLY (oracle).  CPU restatement of the reference's tree search for American
-// checkers, num_threads = 1:
+// TEST INFRASTRUCTURE ONLY (oracle).  CPU restatement of the reference's tree search, num_threads = 1,
+// as a template over the game (American checkers: pinned as below; Go 19x19: the same search over the
+// BUILD-DEFINED Go rules of oracle/go.c - there is no Go in the reference, parity vs ELF unpinned):
 //   elf/ai/tree_search/tree_search.h:112-152,241-378 (run / batch_rollouts / single_rollout),
 //   tree_search_node.h:98-422,436-609 (NodeT, TreeT), tree_search_base.h:137-216,284-367
 //   (EdgeInfo::getScore, MCTSResultT::addActions), mcts.h:81-105,167-202 (act / align_state),
@@ -21,6 +22,7 @@
 #include <vector>
 
 #include "american.h"
+#include "go.h"
 
 namespace {
 
@@ -42,22 +44,32 @@ struct Edge {  // EdgeInfo tree_search_base.h:137-159
   explicit Edge(float p) : prior(p), child(-1), reward(0), num_visits(0), virtual_loss(0) {}
 };
 
-struct Node {  // NodeT tree_search_node.h:98-115,323-334
+template <class State>
+struct NodeT {  // NodeT tree_search_node.h:98-115,323-334
   int status = 0;  // 0 NOT_VISITED, 1 EVAL_REQUESTED, 2 VISITED
   int numVisits = 0;
   float V = 0.f, meanQ = 0.f, parentQ = 0.f;
   bool flip = false;
   std::unordered_map<Action, Edge> edges;
-  std::unique_ptr<am_game> state;
-  explicit Node(float pq) : meanQ(pq), parentQ(pq) {}
+  std::unique_ptr<State> state;
+  explicit NodeT(float pq) : meanQ(pq), parentQ(pq) {}
 };
 
 struct Response { std::vector<std::pair<Action, float>> pi; float value = 0; bool q_flip = false; };
 
-uint64_t state_hash(const am_state& b) {
+uint64_t words_hash(const uint64_t* w, int n) {
   uint64_t h = 0x1234567ull;
-  for (int i = 0; i < 6; ++i) h = elf_splitmix64(h ^ b.w[i]);
+  for (int i = 0; i < n; ++i) h = elf_splitmix64(h ^ w[i]);
   return h;
+}
+
+void scripted(uint64_t h, int na, float* pi, float* v) {
+  for (int i = 0; i < na; ++i) {
+    uint64_t r = elf_splitmix64(h + (uint64_t)i);
+    pi[i] = (float)((r & 1023) + 1) / 1024.0f;
+  }
+  uint64_t r = elf_splitmix64(h + 1000);
+  *v = ((float)(r & 2047) - 1024.0f) / 1024.0f;
 }
 
 }  // namespace
@@ -67,23 +79,52 @@ extern "C" {
 // Scripted network stand-in: pi on a 2^-10 grid (ties do occur), V on a 2^-10 grid in (-1,1), so
 // every float sum in the search is exact and the result is independent of backup order.
 void omcts_scripted_policy(const uint64_t* board6, uint64_t seed, float* pi170, float* v) {
-  am_state b; memcpy(b.w, board6, sizeof(b.w));
-  uint64_t h = state_hash(b) ^ seed;
-  for (int i = 0; i < AM_NUM_ACTIONS; ++i) {
-    uint64_t r = elf_splitmix64(h + (uint64_t)i);
-    pi170[i] = (float)((r & 1023) + 1) / 1024.0f;
-  }
-  uint64_t r = elf_splitmix64(h + 1000);
-  *v = ((float)(r & 2047) - 1024.0f) / 1024.0f;
+  scripted(words_hash(board6, 6) ^ seed, AM_NUM_ACTIONS, pi170, v);
+}
+// the same for Go, keyed on the 22 exported state words (go_export)
+void ogomcts_scripted_policy(const uint64_t* state22, uint64_t seed, float* pi362, float* v) {
+  scripted(words_hash(state22, GO_STATE_WORDS) ^ seed, GO_ACTIONS, pi362, v);
 }
 
 }  // extern "C"
 
 namespace {
 
+struct AmTraits {
+  using State = am_game;
+  static constexpr int NA = AM_NUM_ACTIONS, MW = 3;
+  static bool flip(const State& s) { return (s.board.w[4] & 1) == 1; }          // currentPlayer == WHITE
+  static bool terminated(const State& s) { return am_game_terminated(&s); }
+  static float evaluate(const State& s) { return am_game_evaluate(&s); }
+  static void legal(const State& s, uint64_t* m) { am_legal_mask(&s.board, m); }
+  static bool forward(State& s, int a) { return am_game_forward(&s, a); }
+  static void policy(const State& s, uint64_t seed, float* pi, float* v) { omcts_scripted_policy(s.board.w, seed, pi, v); }
+  static bool same(const State& a, const State& b) { return memcmp(a.board.w, b.board.w, sizeof(a.board.w)) == 0; }
+};
+
+struct GoTraits {
+  using State = go_state;
+  static constexpr int NA = GO_ACTIONS, MW = 6;
+  static bool flip(const State& s) { return s.to_move == 1; }
+  static bool terminated(const State& s) { return go_terminated(&s); }
+  static float evaluate(const State& s) { return go_evaluate(&s); }
+  static void legal(const State& s, uint64_t* m) { go_legal_mask(&s, m); }
+  static bool forward(State& s, int a) { return go_forward(&s, a); }
+  static void policy(const State& s, uint64_t seed, float* pi, float* v) {
+    uint64_t w[GO_STATE_WORDS]; go_export(&s, w); ogomcts_scripted_policy(w, seed, pi, v);
+  }
+  static bool same(const State& a, const State& b) {
+    uint64_t wa[GO_STATE_WORDS], wb[GO_STATE_WORDS]; go_export(&a, wa); go_export(&b, wb);
+    return memcmp(wa, wb, sizeof(wa)) == 0;
+  }
+};
+
+template <class G>
 struct Mcts {
+  using State = typename G::State;
+  using Node = NodeT<State>;
   TsOptions opt;
-  int policy_kind;  // 0 uniform (pi = 1/170, V = 0), 1 scripted
+  int policy_kind;  // 0 uniform (pi = 1/num_actions, V = 0), 1 scripted
   uint64_t policy_seed;
   std::unordered_map<int, std::unique_ptr<Node>> nodes;  // TreeT::allocatedNodes_
   int next_id = 0, root = -1;
@@ -110,20 +151,20 @@ struct Mcts {
   }
 
   // MCTSGameActor.h:198-218 + :256-335
-  void evaluate(const am_game& s, Response* resp) {
-    resp->q_flip = (s.board.w[4] & 1) == 1;
+  void evaluate(const State& s, Response* resp) {
+    resp->q_flip = G::flip(s);
     resp->pi.clear();
-    if (am_game_terminated(&s)) { resp->value = am_game_evaluate(&s) > 0 ? 1.0f : -1.0f; return; }
+    if (G::terminated(s)) { resp->value = G::evaluate(s) > 0 ? 1.0f : -1.0f; return; }
     ++evals;
-    float pi[AM_NUM_ACTIONS], v = 0.f;
-    if (policy_kind == 0) { for (int i = 0; i < AM_NUM_ACTIONS; ++i) pi[i] = 1.0f / 170.0f; }
-    else omcts_scripted_policy(s.board.w, policy_seed, pi, &v);
+    float pi[G::NA], v = 0.f;
+    if (policy_kind == 0) { for (int i = 0; i < G::NA; ++i) pi[i] = 1.0f / (float)G::NA; }
+    else G::policy(s, policy_seed, pi, &v);
     resp->value = v;
     std::vector<std::pair<Action, float>> all;
-    for (int i = 0; i < AM_NUM_ACTIONS; ++i) all.push_back(std::make_pair((Action)i, pi[i]));
+    for (int i = 0; i < G::NA; ++i) all.push_back(std::make_pair((Action)i, pi[i]));
     using dt = std::pair<Action, float>;
     std::sort(all.begin(), all.end(), [](const dt& a, const dt& b) { return a.second > b.second; });
-    uint64_t m[3]; am_legal_mask(&s.board, m);
+    uint64_t m[G::MW]; G::legal(s, m);
     for (auto& p : all) if ((m[p.first >> 6] >> (p.first & 63)) & 1) resp->pi.push_back(p);
     float total = 1e-10;
     for (auto& p : resp->pi) total += p.second;
@@ -169,8 +210,8 @@ struct Mcts {
       Node* next = get(e.child);
       if (!next) break;
       if (!next->state) {  // allocateState tree_search.h:209-224
-        std::unique_ptr<am_game> st(new am_game(*node->state));
-        if (!am_game_forward(st.get(), a)) break;  // NODE_STATE_INVALID (cannot happen: edges are legal)
+        std::unique_ptr<State> st(new State(*node->state));
+        if (!G::forward(*st, a)) break;  // NODE_STATE_INVALID (cannot happen: edges are legal)
         next->state = std::move(st);
       }
       node = next; ++depth;
@@ -212,30 +253,24 @@ struct Mcts {
   }
 };
 
-}  // namespace
-
-extern "C" {
-
-void* omcts_create(const int* iopt, float c_puct, int policy_kind, uint64_t policy_seed) {
-  Mcts* m = new Mcts();
+template <class G>
+void* create(const int* iopt, float c_puct, int policy_kind, uint64_t policy_seed) {
+  Mcts<G>* m = new Mcts<G>();
   m->opt = TsOptions{iopt[0], iopt[1], iopt[2], iopt[3], c_puct, iopt[4], iopt[5], iopt[6], iopt[7]};
   m->policy_kind = policy_kind; m->policy_seed = policy_seed;
   return m;
 }
-void omcts_destroy(void* h) { delete (Mcts*)h; }
-void omcts_clear(void* h) { ((Mcts*)h)->clear(); }                       // MCTSAI_T::resetTree / endGame
-void omcts_advance(void* h, int action) { ((Mcts*)h)->tree_advance((Action)action); }  // advanceMoves
-void omcts_stats(void* h, long* out4) { Mcts* m = (Mcts*)h; out4[0] = m->rollouts; out4[1] = m->evals; out4[2] = m->depth_sum; out4[3] = m->edge_sum; }
 
 // MCTSAI_T::act -> TreeSearchT::run + chooseAction.  Edges are reported in the unordered_map's
 // iteration order.  Returns best action (most_visited: first strict max in that order).
-int omcts_run(void* h, const am_game* g, int max_edges, int* n_edges, uint16_t* actions, int* visits,
-              float* rewards, float* priors, int* total_visits, float* root_value, float* best_q) {
-  Mcts* m = (Mcts*)h;
+template <class G>
+int run(Mcts<G>* m, const typename G::State* g, int max_edges, int* n_edges, uint16_t* actions, int* visits,
+        float* rewards, float* priors, int* total_visits, float* root_value, float* best_q) {
+  using State = typename G::State;
   if (!m->opt.persistent_tree) m->clear();
-  Node* rootn = m->get(m->root);
-  if (!rootn->state) rootn->state.reset(new am_game(*g));   // setRootNodeState
-  if (memcmp(rootn->state->board.w, g->board.w, sizeof(g->board.w)) != 0) return -2;  // "Root state is not the same"
+  auto* rootn = m->get(m->root);
+  if (!rootn->state) rootn->state.reset(new State(*g));   // setRootNodeState
+  if (!G::same(*rootn->state, *g)) return -2;              // "Root state is not the same"
   for (int idx = 0; idx < m->opt.num_rollouts; idx += m->opt.num_rollouts_per_batch) m->batch_rollouts(rootn);
   // MCTSResultT::addActions tree_search_base.h:310-367
   float max_score = std::numeric_limits<float>::lowest();
@@ -251,6 +286,34 @@ int omcts_run(void* h, const am_game* g, int max_edges, int* n_edges, uint16_t* 
   // MCTSGameAI::getValue MCTSGameAI.h:40-46
   *best_q = (tv == 0 || !beste) ? rootn->V : beste->reward / beste->num_visits;
   return k == 0 ? -1 : best;
+}
+
+}  // namespace
+
+extern "C" {
+
+using AmMcts = Mcts<AmTraits>;
+using GoMcts = Mcts<GoTraits>;
+
+void* omcts_create(const int* iopt, float c_puct, int policy_kind, uint64_t policy_seed) { return create<AmTraits>(iopt, c_puct, policy_kind, policy_seed); }
+void omcts_destroy(void* h) { delete (AmMcts*)h; }
+void omcts_clear(void* h) { ((AmMcts*)h)->clear(); }                       // MCTSAI_T::resetTree / endGame
+void omcts_advance(void* h, int action) { ((AmMcts*)h)->tree_advance((Action)action); }  // advanceMoves
+void omcts_stats(void* h, long* out4) { AmMcts* m = (AmMcts*)h; out4[0] = m->rollouts; out4[1] = m->evals; out4[2] = m->depth_sum; out4[3] = m->edge_sum; }
+
+void* ogomcts_create(const int* iopt, float c_puct, int policy_kind, uint64_t policy_seed) { return create<GoTraits>(iopt, c_puct, policy_kind, policy_seed); }
+void ogomcts_destroy(void* h) { delete (GoMcts*)h; }
+void ogomcts_clear(void* h) { ((GoMcts*)h)->clear(); }
+void ogomcts_advance(void* h, int action) { ((GoMcts*)h)->tree_advance((Action)action); }
+void ogomcts_stats(void* h, long* out4) { GoMcts* m = (GoMcts*)h; out4[0] = m->rollouts; out4[1] = m->evals; out4[2] = m->depth_sum; out4[3] = m->edge_sum; }
+int ogomcts_run(void* h, const go_state* g, int max_edges, int* n_edges, uint16_t* actions, int* visits, float* rewards,
+                float* priors, int* total_visits, float* root_value, float* best_q) {
+  return run<GoTraits>((GoMcts*)h, g, max_edges, n_edges, actions, visits, rewards, priors, total_visits, root_value, best_q);
+}
+
+int omcts_run(void* h, const am_game* g, int max_edges, int* n_edges, uint16_t* actions, int* visits,
+              float* rewards, float* priors, int* total_visits, float* root_value, float* best_q) {
+  return run<AmTraits>((AmMcts*)h, g, max_edges, n_edges, actions, visits, rewards, priors, total_visits, root_value, best_q);
 }
 
 // libstdc++ behaviours exposed for checking the HIP path's explicit emulations (tests only)

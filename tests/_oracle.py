@@ -126,6 +126,15 @@ def oracle():
         L.omcts_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _i32p, _u16p, _i32p, _f32p, _f32p, _i32p, _f32p, _f32p]
         L.omcts_run.restype = C.c_int
         L.omcts_scripted_policy.argtypes = [_u64p, C.c_uint64, _f32p, _f32p]
+        L.ogomcts_create.argtypes = [_i32p, C.c_float, C.c_int, C.c_uint64]
+        L.ogomcts_create.restype = C.c_void_p
+        L.ogomcts_destroy.argtypes = [C.c_void_p]
+        L.ogomcts_clear.argtypes = [C.c_void_p]
+        L.ogomcts_advance.argtypes = [C.c_void_p, C.c_int]
+        L.ogomcts_stats.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
+        L.ogomcts_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _i32p, _u16p, _i32p, _f32p, _f32p, _i32p, _f32p, _f32p]
+        L.ogomcts_run.restype = C.c_int
+        L.ogomcts_scripted_policy.argtypes = [_u64p, C.c_uint64, _f32p, _f32p]
         L.omcts_std_sort_desc.argtypes = [C.c_int, _f32p, _u16p]
         L.omcts_std_umap_order.argtypes = [C.c_int, _u16p, _u16p]
         _oracle = L
@@ -334,39 +343,44 @@ def go_grid_to_words(g, to_move=0, ply=0):
 
 
 class OracleMcts:
-    """oracle/mcts.cpp: reference tree search restated (num_threads=1)."""
+    """oracle/mcts.cpp: reference tree search restated (num_threads=1).  game="go": the same search over
+    the build-defined Go rules (state pointer = GoBoards.ptr(i))."""
 
     def __init__(self, num_rollouts=256, rollouts_per_batch=1, virtual_loss=1, use_prior=1, c_puct=1.5,
                  unexplored_q_zero=0, root_unexplored_q_zero=0, persistent_tree=1, pick_method=0,
-                 policy_kind=0, policy_seed=0):
+                 policy_kind=0, policy_seed=0, game="american"):
         self.L = oracle()
+        self.pre = "omcts_" if game == "american" else "ogomcts_"
+        self.cap = 64 if game == "american" else 362
         iopt = np.array([num_rollouts, rollouts_per_batch, virtual_loss, use_prior, unexplored_q_zero,
                          root_unexplored_q_zero, persistent_tree, pick_method], dtype=np.int32)
-        self.h = C.c_void_p(self.L.omcts_create(iopt, c_puct, policy_kind, policy_seed))
+        self.h = C.c_void_p(getattr(self.L, self.pre + "create")(iopt, c_puct, policy_kind, policy_seed))
 
     def __del__(self):
         if getattr(self, "h", None):
-            self.L.omcts_destroy(self.h)
+            getattr(self.L, self.pre + "destroy")(self.h)
             self.h = None
 
     def run(self, game):
-        """game: AmGame. -> dict(best, edges=[(action, visits, reward, prior)], total_visits, root_value, best_q)"""
+        """game: AmGame or a go_state pointer. -> dict(best, edges=[(action, visits, reward, prior)], total_visits, root_value, best_q)"""
         n = np.zeros(1, dtype=np.int32); tv = np.zeros(1, dtype=np.int32)
         rv = np.zeros(1, dtype=np.float32); bq = np.zeros(1, dtype=np.float32)
-        acts = np.zeros(64, dtype=np.uint16); vis = np.zeros(64, dtype=np.int32)
-        rew = np.zeros(64, dtype=np.float32); pri = np.zeros(64, dtype=np.float32)
-        best = self.L.omcts_run(self.h, game.buf, 64, n, acts, vis, rew, pri, tv, rv, bq)
+        cap = self.cap
+        acts = np.zeros(cap, dtype=np.uint16); vis = np.zeros(cap, dtype=np.int32)
+        rew = np.zeros(cap, dtype=np.float32); pri = np.zeros(cap, dtype=np.float32)
+        gp = game.buf if hasattr(game, "buf") else game
+        best = getattr(self.L, self.pre + "run")(self.h, gp, cap, n, acts, vis, rew, pri, tv, rv, bq)
         k = int(n[0])
         return dict(best=best, edges=[(int(acts[i]), int(vis[i]), float(rew[i]), float(pri[i])) for i in range(k)],
                     total_visits=int(tv[0]), root_value=float(rv[0]), best_q=float(bq[0]))
 
     def advance(self, a):
-        self.L.omcts_advance(self.h, int(a))
+        getattr(self.L, self.pre + "advance")(self.h, int(a))
 
     def clear(self):
-        self.L.omcts_clear(self.h)
+        getattr(self.L, self.pre + "clear")(self.h)
 
     def stats(self):
         o = np.zeros(4, dtype=np.int64)
-        self.L.omcts_stats(self.h, o)
+        getattr(self.L, self.pre + "stats")(self.h, o)
         return dict(rollouts=int(o[0]), evals=int(o[1]), depth_sum=int(o[2]), edge_sum=int(o[3]))

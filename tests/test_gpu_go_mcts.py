@@ -1,0 +1,169 @@
+"""GPU parity of the Go tree search (through the C-ABI) against oracle/mcts.cpp instantiated over
+the build-defined Go rules.  Edge order, visit counts, rewards, priors, chosen moves and the
+search statistics are bit-exact; leaf feature planes equal the oracle's for the same move path.
+(The search code is pinned to the compiled reference for checkers; Go itself: parity unpinned.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import _oracle
+from tests._oracle import GoBoards, OracleMcts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _edges(res, i):
+    k = int(res["n_edges"][i])
+    return [(int(res["edge_action"][i, j]), int(res["edge_visits"][i, j]), float(res["edge_reward"][i, j]),
+             float(res["edge_prior"][i, j])) for j in range(k)]
+
+
+def _cpu(res):
+    return {k: v.cpu().numpy() for k, v in res.items()}
+
+
+def _open_games(torch, n, start_plies, seed):
+    from elf_amd.boards import BoardBatch, GO19
+    rng = np.random.default_rng(seed)
+    games = GoBoards(n)
+    bb = BoardBatch(GO19, n)
+    for ply in range(start_plies):
+        acts = np.full(n, -1, dtype=np.int16)
+        for i in range(n):
+            if ply >= (i * 7) % (start_plies + 1):
+                continue
+            legal = [a for a in games.legal(i) if a != 361]
+            acts[i] = legal[rng.integers(len(legal))]
+            assert games.forward(acts[i], i)
+        bb.forward(torch.tensor(acts, device="cuda"))
+    assert np.array_equal(bb.export_states(), games.export_all())
+    return games, bb
+
+
+def _play(torch, n, nmoves, opts, policy_kind, seed, start_plies, max_nodes=0, max_edges=0):
+    from elf_amd.boards import GO19
+    from elf_amd.mcts import TreeSearchBatch
+    L = _oracle.oracle()
+    games, bb = _open_games(torch, n, start_plies, seed)
+    ts = TreeSearchBatch(GO19, n, max_nodes=max_nodes, max_edges=max_edges, **opts)
+    oopts = dict(num_rollouts=opts["num_rollouts_per_thread"], rollouts_per_batch=opts["num_rollouts_per_batch"],
+                 virtual_loss=opts["virtual_loss"], c_puct=opts["c_puct"],
+                 root_unexplored_q_zero=int(opts.get("root_unexplored_q_zero", False)),
+                 persistent_tree=int(opts.get("persistent_tree", True)))
+    oracles = [OracleMcts(policy_kind=policy_kind, policy_seed=seed, game="go", **oopts) for _ in range(n)]
+    B = opts["num_rollouts_per_batch"]
+
+    def evaluator(feat, states, need):
+        s = states.cpu().numpy().view(np.uint64).reshape(n * B, 22)
+        nd = need.cpu().numpy().reshape(-1)
+        pi = np.zeros((n * B, 362), dtype=np.float32); v = np.zeros(n * B, dtype=np.float32)
+        vv = np.zeros(1, dtype=np.float32)
+        for k in range(n * B):
+            if nd[k]:
+                L.ogomcts_scripted_policy(np.ascontiguousarray(s[k]), seed, pi[k], vv)
+                v[k] = vv[0]
+        return torch.tensor(pi, device="cuda"), torch.tensor(v, device="cuda")
+
+    for mv in range(nmoves):
+        assert ts.set_roots(bb).cpu().numpy().all()
+        if policy_kind == 0:
+            ts.run_uniform()
+        else:
+            ts.run(evaluator)
+        res = _cpu(ts.result(edge_cap=362, with_policy=True))
+        assert not ts.stats()[1].cpu().numpy().any(), "a tree ran out of node / edge arena"
+        acts = np.full(n, -1, dtype=np.int16)
+        for i, o in enumerate(oracles):
+            r = o.run(games.ptr(i))
+            assert _edges(res, i) == r["edges"], (mv, i)
+            assert int(res["total_visits"][i]) == r["total_visits"] and float(res["root_value"][i]) == r["root_value"]
+            pol = np.zeros(362, dtype=np.int32)
+            for (a, vis, _, _) in r["edges"]:
+                pol[a] = vis
+            assert np.array_equal(res["policy_visits"][i], pol)
+            if r["edges"]:
+                assert int(res["best"][i]) == r["best"], (mv, i)
+                acts[i] = r["best"]
+                assert games.forward(r["best"], i)
+                o.advance(r["best"])
+            else:
+                assert int(res["best"][i]) == -1
+        act = torch.tensor(acts, device="cuda")
+        bb.forward(act)
+        ts.treeAdvance(act)
+        assert np.array_equal(bb.export_states(), games.export_all())
+    st, flags = ts.stats()
+    assert not flags.cpu().numpy().any()
+    tot = {k: sum(o.stats()[k] for o in oracles) for k in ("rollouts", "evals", "depth_sum", "edge_sum")}
+    assert st == tot, (st, tot)
+
+
+def test_go_uniform_policy(torch_cuda):
+    _play(torch_cuda, 8, 4, dict(num_rollouts_per_thread=48, num_rollouts_per_batch=4, virtual_loss=1, c_puct=1.5),
+          policy_kind=0, seed=3, start_plies=40, max_nodes=512, max_edges=160000)
+
+
+def test_go_scripted_network_batch1_and_batch8(torch_cuda):
+    _play(torch_cuda, 6, 4, dict(num_rollouts_per_thread=40, num_rollouts_per_batch=1, virtual_loss=2, c_puct=0.9),
+          policy_kind=1, seed=11, start_plies=30, max_nodes=512, max_edges=160000)
+    _play(torch_cuda, 6, 4, dict(num_rollouts_per_thread=64, num_rollouts_per_batch=8, virtual_loss=1, c_puct=1.5,
+                                 root_unexplored_q_zero=True),
+          policy_kind=1, seed=5, start_plies=60, max_nodes=512, max_edges=160000)
+
+
+def test_go_late_game_captures_ko_and_passes(torch_cuda):
+    """Crowded boards: captures, ko and suicide exclusions inside the tree; pass edges get visited
+    so two-pass terminal leaves (Tromp-Taylor value) occur."""
+    _play(torch_cuda, 6, 5, dict(num_rollouts_per_thread=96, num_rollouts_per_batch=4, virtual_loss=1, c_puct=1.5,
+                                 persistent_tree=False),
+          policy_kind=1, seed=9, start_plies=330, max_nodes=512, max_edges=100000)
+
+
+def test_go_leaf_features_follow_the_path(torch_cuda):
+    """A peaked policy makes the search walk one line ever deeper; each new leaf's 18 planes must
+    equal the oracle's planes after the same moves (8-deep history across the root into the game)."""
+    torch = torch_cuda
+    from elf_amd.boards import GO19
+    from elf_amd.mcts import TreeSearchBatch
+    L = _oracle.oracle()
+    n = 3
+    games, bb = _open_games(torch, n, 5, seed=21)
+    ts = TreeSearchBatch(GO19, n, num_rollouts_per_thread=12, num_rollouts_per_batch=1, virtual_loss=0, c_puct=5.0,
+                         max_nodes=64, max_edges=8000)
+    assert ts.set_roots(bb).cpu().numpy().all()
+    cur = GoBoards(n)
+    C.memmove(cur.buf, games.buf, games.sz * n)
+    depth_seen = 0
+    for step in range(12):
+        st, ft, ne = ts.select(want_states=True, want_features=True)
+        st = st.cpu().numpy().view(np.uint64).reshape(n, 22); ft = ft.cpu().numpy().reshape(n, 18, 19, 19)
+        ne = ne.cpu().numpy().reshape(n)
+        pi = np.full((n, 362), 1e-4, dtype=np.float32)
+        for i in range(n):
+            assert ne[i] == 1
+            if step > 0:   # the leaf is a child of the previous leaf: find the move
+                found = False
+                for a in cur.legal(i):
+                    tmp = GoBoards(1)
+                    C.memmove(tmp.buf, cur.ptr(i), cur.sz)
+                    tmp.forward(a)
+                    if np.array_equal(tmp.export(0), st[i]):
+                        C.memmove(cur.ptr(i), tmp.buf, cur.sz)
+                        found = True
+                        break
+                assert found, (step, i)
+            assert np.array_equal(cur.export(i), st[i])
+            assert np.array_equal(cur.features(i), ft[i]), (step, i)
+            fav = [a for a in cur.legal(i) if a != 361][(7 * step + i) % 50]
+            pi[i, fav] = 0.9
+        depth_seen = step
+        ts.backup(torch.tensor(pi, device="cuda"), torch.zeros(n, dtype=torch.float32, device="cuda"))
+    assert depth_seen == 11
