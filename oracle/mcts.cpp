@@ -100,6 +100,7 @@ struct AmTraits {
   static bool forward(State& s, int a) { return am_game_forward(&s, a); }
   static void policy(const State& s, uint64_t seed, float* pi, float* v) { omcts_scripted_policy(s.board.w, seed, pi, v); }
   static bool same(const State& a, const State& b) { return memcmp(a.board.w, b.board.w, sizeof(a.board.w)) == 0; }
+  static void words(const State& s, uint64_t* w) { memcpy(w, s.board.w, sizeof(s.board.w)); }
 };
 
 struct GoTraits {
@@ -117,6 +118,7 @@ struct GoTraits {
     uint64_t wa[GO_STATE_WORDS], wb[GO_STATE_WORDS]; go_export(&a, wa); go_export(&b, wb);
     return memcmp(wa, wb, sizeof(wa)) == 0;
   }
+  static void words(const State& s, uint64_t* w) { go_export(&s, w); }
 };
 
 template <class G>
@@ -124,7 +126,8 @@ struct Mcts {
   using State = typename G::State;
   using Node = NodeT<State>;
   TsOptions opt;
-  int policy_kind;  // 0 uniform (pi = 1/num_actions, V = 0), 1 scripted
+  int policy_kind;  // 0 uniform (pi = 1/num_actions, V = 0), 1 scripted, 2 caller's callback (recorded network outputs)
+  void (*policy_cb)(const uint64_t* state_words, float* pi, float* v) = nullptr;
   uint64_t policy_seed;
   std::unordered_map<int, std::unique_ptr<Node>> nodes;  // TreeT::allocatedNodes_
   int next_id = 0, root = -1;
@@ -158,6 +161,7 @@ struct Mcts {
     ++evals;
     float pi[G::NA], v = 0.f;
     if (policy_kind == 0) { for (int i = 0; i < G::NA; ++i) pi[i] = 1.0f / (float)G::NA; }
+    else if (policy_kind == 2) { uint64_t w[32]; G::words(s, w); policy_cb(w, pi, &v); }
     else G::policy(s, policy_seed, pi, &v);
     resp->value = v;
     std::vector<std::pair<Action, float>> all;
@@ -296,12 +300,14 @@ using AmMcts = Mcts<AmTraits>;
 using GoMcts = Mcts<GoTraits>;
 
 void* omcts_create(const int* iopt, float c_puct, int policy_kind, uint64_t policy_seed) { return create<AmTraits>(iopt, c_puct, policy_kind, policy_seed); }
+void omcts_set_callback(void* h, void (*cb)(const uint64_t*, float*, float*)) { ((AmMcts*)h)->policy_cb = cb; }
 void omcts_destroy(void* h) { delete (AmMcts*)h; }
 void omcts_clear(void* h) { ((AmMcts*)h)->clear(); }                       // MCTSAI_T::resetTree / endGame
 void omcts_advance(void* h, int action) { ((AmMcts*)h)->tree_advance((Action)action); }  // advanceMoves
 void omcts_stats(void* h, long* out4) { AmMcts* m = (AmMcts*)h; out4[0] = m->rollouts; out4[1] = m->evals; out4[2] = m->depth_sum; out4[3] = m->edge_sum; }
 
 void* ogomcts_create(const int* iopt, float c_puct, int policy_kind, uint64_t policy_seed) { return create<GoTraits>(iopt, c_puct, policy_kind, policy_seed); }
+void ogomcts_set_callback(void* h, void (*cb)(const uint64_t*, float*, float*)) { ((GoMcts*)h)->policy_cb = cb; }
 void ogomcts_destroy(void* h) { delete (GoMcts*)h; }
 void ogomcts_clear(void* h) { ((GoMcts*)h)->clear(); }
 void ogomcts_advance(void* h, int action) { ((GoMcts*)h)->tree_advance((Action)action); }

@@ -356,6 +356,20 @@ class OracleMcts:
                          root_unexplored_q_zero, persistent_tree, pick_method], dtype=np.int32)
         self.h = C.c_void_p(getattr(self.L, self.pre + "create")(iopt, c_puct, policy_kind, policy_seed))
 
+    POLICY_CB = C.CFUNCTYPE(None, C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_float))
+
+    def set_callback(self, fn, state_words, num_actions):
+        """policy_kind=2: fn(state_words ndarray[u64]) -> (pi ndarray[f32, num_actions], v float)"""
+        def tramp(wp, pip, vp):
+            w = np.ctypeslib.as_array(wp, shape=(state_words,)).copy()
+            pi, v = fn(w)
+            np.ctypeslib.as_array(pip, shape=(num_actions,))[:] = pi
+            vp[0] = v
+        self._cb = self.POLICY_CB(tramp)   # keep alive
+        f = getattr(self.L, self.pre + "set_callback")
+        f.argtypes = [C.c_void_p, self.POLICY_CB]
+        f(self.h, self._cb)
+
     def __del__(self):
         if getattr(self, "h", None):
             getattr(self.L, self.pre + "destroy")(self.h)
