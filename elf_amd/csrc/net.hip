@@ -14,6 +14,7 @@
 // Bias (+ residual) + ReLU are fused in the epilogue.  Heads run in fp32.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -132,6 +133,138 @@ conv3x3_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, c
   }
 }
 
+
+// Board-tiled 3x3 convolution (the fast path for 19x19 and 8x8): one 512-thread workgroup owns NBW
+// whole boards.  For every 32-channel input chunk the padded activations of those boards are staged
+// in LDS ONCE and serve all nine taps (a tap is just a row offset in the padded board), so HBM/L2
+// sees each activation once per layer instead of nine times; the per-tap weight slices stream
+// through a second LDS buffer.  Staging is LDS-DMA (global_load_lds_dwordx4: no staging registers,
+// no ds_write pass), double-buffered: the DMA of stage s+1 is in flight while stage s runs on the
+// matrix cores, one barrier per stage.  An LDS-DMA wave-instruction writes 1 KiB lane-linearly, so
+// rows are unpadded 64 B and bank conflicts are avoided by an XOR swizzle of the 16-byte chunk index
+// applied on the SOURCE address (slot = chunk ^ ((row >> 2) & 3)) and again when fragments are read.
+// Wave grid 2 (output-channel halves) x 4 (position quarters); a wave keeps COUT/32 x NTW
+// accumulator tiles (16x16 fp32) in registers, so each LDS fragment read feeds 6-7 MFMAs.
+template <int COUT, int H, int NBW>
+__global__ void __launch_bounds__(512)
+conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
+                     const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int B, int CIN, int relu) {
+  constexpr int PW = H + 2, PP = PW * PW, HW = H * H;
+  constexpr int PT = NBW * HW;             // output positions of this workgroup
+  constexpr int NT = (PT + 15) / 16;       // position tiles
+  constexpr int NTW = (NT + 3) / 4;        // per wave
+  constexpr int MTW = COUT / 32;           // output-channel tiles per wave (half of COUT)
+  constexpr int XROWS = NBW * PP;
+  constexpr int XI = (XROWS * 4 + 63) / 64;   // 1-KiB DMA pieces per activation chunk
+  constexpr int AI = COUT * 4 / 64;           // ... per weight slice (COUT is a multiple of 16)
+  constexpr int XBUF = XI * 512, ABUF = AI * 512;   // u16 elements per buffer
+  extern __shared__ __attribute__((aligned(1024))) uint16_t smem[];
+  uint16_t* sA = smem;                 // [2][ABUF]
+  uint16_t* sX = smem + 2 * ABUF;      // [2][XBUF]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave & 1, wp = wave >> 1;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int board0 = blockIdx.x * NBW;
+  const long xrow0 = (long)board0 * PP;
+  const long xrow_max = (long)B * PP - 1;
+
+  int pbase[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    int p = (wp * NTW + nt) * 16 + r16;
+    p = p < PT ? p : PT - 1;
+    const int bl = p / HW, rem = p % HW, y = rem / H, xw = rem % H;
+    pbase[nt] = bl * PP + (y + 1) * PW + xw + 1;
+  }
+  f32x4 acc[MTW][NTW];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+  // DMA issue: piece j covers LDS slots [64j, 64j+64); slot e = row*4 + (chunk ^ ((row>>2)&3))
+  auto dma_x = [&](int c0, int buf) {
+#pragma unroll
+    for (int i = 0; i < (XI + 7) / 8; ++i) {
+      const int j = wave + 8 * i;
+      if (j < XI) {
+        const int e = j * 64 + lane, row = e >> 2, ch = (e & 3) ^ ((row >> 2) & 3);
+        long grow = xrow0 + row;
+        grow = grow < xrow_max ? grow : xrow_max;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + grow * CIN + c0 + ch * 8),
+                                         (__attribute__((address_space(3))) void*)(sX + (size_t)buf * XBUF + j * 512), 16, 0, 0);
+      }
+    }
+  };
+  auto dma_a = [&](int tap, int c0, int buf) {
+#pragma unroll
+    for (int i = 0; i < (AI + 7) / 8; ++i) {
+      const int j = wave + 8 * i;
+      if (j < AI) {
+        const int e = j * 64 + lane, row = e >> 2, ch = (e & 3) ^ ((row >> 2) & 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + ((size_t)tap * COUT + row) * CIN + c0 + ch * 8),
+                                         (__attribute__((address_space(3))) void*)(sA + (size_t)buf * ABUF + j * 512), 16, 0, 0);
+      }
+    }
+  };
+
+  const int nchunk = CIN / KC, nstage = nchunk * 9;
+  dma_x(0, 0); dma_a(0, 0, 0);
+  __syncthreads();
+  const int aswz = (q ^ ((r16 >> 2) & 3)) * 8;   // (row >> 2) & 3 of an A row only depends on r16
+  for (int s = 0; s < nstage; ++s) {
+    const int chunk = s / 9, tap = s - chunk * 9;
+    if (s + 1 < nstage) {
+      dma_a(tap == 8 ? 0 : tap + 1, (tap == 8 ? chunk + 1 : chunk) * KC, (s + 1) & 1);
+      if (tap == 8) dma_x((chunk + 1) * KC, (chunk + 1) & 1);
+    }
+    {
+      const uint16_t* A = sA + (size_t)(s & 1) * ABUF + (wc * MTW * 16 + r16) * 32 + aswz;
+      const uint16_t* X = sX + (size_t)(chunk & 1) * XBUF;
+      const int toff = (tap / 3 - 1) * PW + (tap % 3 - 1);
+      bf16x8 a[MTW];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) a[mt] = *(const bf16x8*)(A + mt * 16 * 32);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int row = pbase[nt] + toff;
+        const bf16x8 b = *(const bf16x8*)(X + row * 32 + ((q ^ ((row >> 2) & 3)) * 8));
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();   // also retires this wave's DMA (vmcnt(0)) before anyone reads the other buffers
+  }
+  // epilogue: lane holds position r16 of each position tile, channels 4*q+reg of each channel tile
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int p = (wp * NTW + nt) * 16 + r16;
+    const int bl = p / HW;
+    if (p >= PT || board0 + bl >= B) continue;
+    const size_t obase = (size_t)(xrow0 + pbase[nt]) * COUT;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+      const int co = (wc * MTW + mt) * 16 + q * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] + bias[co + r];
+      if (res) {
+        const uint2 rr = *(const uint2*)(res + obase + co);
+        v[0] += bf2f((uint16_t)(rr.x & 0xFFFF)); v[1] += bf2f((uint16_t)(rr.x >> 16));
+        v[2] += bf2f((uint16_t)(rr.y & 0xFFFF)); v[3] += bf2f((uint16_t)(rr.y >> 16));
+      }
+      if (relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      uint2 o;
+      o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+      o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      *(uint2*)(out + obase + co) = o;
+    }
+  }
+}
+
 // Heads (model_american_checkers.py:339-347), fp32.  One workgroup per board.
 //   pi  = exp(logsoftmax(pi_linear(relu(bn(conv1x1_pi(s))))))     V = tanh(lin2(relu(lin1(relu(bn(conv1x1_v(s)))))))
 __global__ void __launch_bounds__(256)
@@ -228,6 +361,7 @@ struct NetImpl {
   float bpi = 0, bv = 0, v2_b = 0;
   uint16_t *xin = nullptr, *act[3] = {nullptr, nullptr, nullptr};
   bool loaded = false;
+  bool use_board_kernel = true;   // ELFHIP_NET_TILE=positions selects the generic position-tiled kernel
   ~NetImpl() { for (void* p : allocs) (void)hipFree(p); }
 
   size_t param_count() const {
@@ -311,7 +445,35 @@ struct NetImpl {
     hipLaunchKernelGGL(conv3x3_kernel<COUT>, dim3((M + BP - 1) / BP), dim3(256), 0, stream, x, c.w, c.b, res, out, B,
                        cfg.board, cfg.board, c.cin, relu);
   }
+  template <int COUT, int H, int NBW>
+  void launch_board(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
+    constexpr size_t smem = ((size_t)2 * (COUT * 4 / 64) * 512 + (size_t)2 * ((NBW * (H + 2) * (H + 2) * 4 + 63) / 64) * 512) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv3x3_board_kernel<COUT, H, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_board_kernel<COUT, H, NBW>), dim3((B + NBW - 1) / NBW), dim3(512), smem, stream, x, c.w, c.b, res,
+                       out, B, c.cin, relu);
+  }
+  template <int COUT>
+  bool conv_board(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
+    if (cfg.board == 19) { launch_board<COUT, 19, 1>(x, c, res, out, B, relu); return true; }
+    if (cfg.board == 8) { launch_board<COUT, 8, 4>(x, c, res, out, B, relu); return true; }
+    return false;
+  }
   void conv(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
+    if (use_board_kernel) {
+      bool done = false;
+      switch (cfg.dim) {
+        case 32: done = conv_board<32>(x, c, res, out, B, relu); break;
+        case 64: done = conv_board<64>(x, c, res, out, B, relu); break;
+        case 128: done = conv_board<128>(x, c, res, out, B, relu); break;
+        case 224: done = conv_board<224>(x, c, res, out, B, relu); break;
+        default: done = cfg.board == 8 && conv_board<256>(x, c, res, out, B, relu); break;  // 256 x 19x19 would spill
+      }
+      if (done) return;
+    }
     switch (cfg.dim) {
       case 32: launch_conv<32>(x, c, res, out, B, relu); break;
       case 64: launch_conv<64>(x, c, res, out, B, relu); break;
@@ -367,6 +529,7 @@ int elfhip_net_create(const elfhip_net_config* cfg, int max_batch, int device, e
   NetImpl* n = new (std::nothrow) NetImpl();
   if (!n) { elfhip_set_error("net_create: host allocation failed"); return ELFHIP_ENOMEM; }
   n->cfg = *cfg; n->device = device; n->max_batch = max_batch;
+  { const char* e = getenv("ELFHIP_NET_TILE"); if (e && !strcmp(e, "positions")) n->use_board_kernel = false; }
   int rc = n->alloc();
   if (rc != ELFHIP_OK) { delete n; return rc; }
   *out = new elfhip_net{n};
