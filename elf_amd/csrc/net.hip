@@ -134,15 +134,41 @@ conv3x3_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, c
 }
 
 
+// s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: all but the n most recent VMEM operations of
+// this wave have completed.  The immediate must be a literal.
+__device__ inline void wait_vmcnt(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
 // Board-tiled 3x3 convolution (the fast path for 19x19 and 8x8): one 512-thread workgroup owns NBW
-// whole boards.  For every 32-channel input chunk the padded activations of those boards are staged
-// in LDS ONCE and serve all nine taps (a tap is just a row offset in the padded board), so HBM/L2
-// sees each activation once per layer instead of nine times; the per-tap weight slices stream
-// through a second LDS buffer.  Staging is LDS-DMA (global_load_lds_dwordx4: no staging registers,
-// no ds_write pass), double-buffered: the DMA of stage s+1 is in flight while stage s runs on the
-// matrix cores, one barrier per stage.  An LDS-DMA wave-instruction writes 1 KiB lane-linearly, so
-// rows are unpadded 64 B and bank conflicts are avoided by an XOR swizzle of the 16-byte chunk index
-// applied on the SOURCE address (slot = chunk ^ ((row >> 2) & 3)) and again when fragments are read.
+// whole boards.  For every 32-channel input chunk the activations of those boards are staged in LDS
+// ONCE and serve all nine taps, so HBM/L2 sees each activation once per layer instead of nine
+// times; the per-tap weight slices stream through a 3-deep LDS ring.
+//
+// Staging is LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass).  A DMA
+// wave-instruction writes 1 KiB lane-linearly but its 64 SOURCE addresses are free, so the LDS image
+// is chosen for the reader: a 1-KiB piece holds 16 rows (positions or output channels) x 32 channels
+// as [16-byte chunk q][row & 15]; row r, chunk q lives at (r >> 4) * 1024 + q * 256 + (r & 15) * 16.
+// Every ds_read_b128 lane group then covers 16 consecutive rows = 16 distinct bank slots: conflict
+// free for the weight fragments and for the activation fragments at every tap, because the
+// activation image is the UNPADDED board (row = b*H*H + y*H + x; a tap is the constant row offset
+// dy*H + dx) and lanes whose neighbour falls off the board read a zero block at their own slot.
+//
+// Pipeline: weights two stages ahead, the next activation chunk five stages ahead (issued at tap
+// 4); DMA stays in flight across the per-stage barrier - a wave retires only what the NEXT stage
+// reads with a counted s_waitcnt vmcnt(N), then a raw s_barrier publishes it.  Activation
+// fragments are read two position tiles ahead of the MFMAs that consume them.
 // Wave grid 2 (output-channel halves) x 4 (position quarters); a wave keeps COUT/32 x NTW
 // accumulator tiles (16x16 fp32) in registers, so each LDS fragment read feeds 6-7 MFMAs.
 template <int COUT, int H, int NBW>
@@ -154,104 +180,158 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
   constexpr int NT = (PT + 15) / 16;       // position tiles
   constexpr int NTW = (NT + 3) / 4;        // per wave
   constexpr int MTW = COUT / 32;           // output-channel tiles per wave (half of COUT)
-  constexpr int XROWS = NBW * PP;
-  constexpr int XI = (XROWS * 4 + 63) / 64;   // 1-KiB DMA pieces per activation chunk
-  constexpr int AI = COUT * 4 / 64;           // ... per weight slice (COUT is a multiple of 16)
+  constexpr int XI = NT;                   // 1-KiB DMA pieces per activation chunk
+  constexpr int AI = COUT / 16;            // ... per weight slice
   constexpr int XBUF = XI * 512, ABUF = AI * 512;   // u16 elements per buffer
+  constexpr int NXW = (XI + 7) / 8, NAW = (AI + 7) / 8;
   extern __shared__ __attribute__((aligned(1024))) uint16_t smem[];
-  uint16_t* sA = smem;                 // [2][ABUF]
-  uint16_t* sX = smem + 2 * ABUF;      // [2][XBUF]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint16_t* sA = smem;                 // [3][ABUF]
+  uint16_t* sX = smem + 3 * ABUF;      // [2][XBUF]
+  uint16_t* sZ = sX + 2 * XBUF;        // [512] zeros
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave & 1, wp = wave >> 1;
   const int r16 = lane & 15, q = lane >> 4;
   const int board0 = blockIdx.x * NBW;
   const long xrow0 = (long)board0 * PP;
-  const long xrow_max = (long)B * PP - 1;
+  const int rows_left = (int)min((long)NBW * PP, (long)B * PP - xrow0);   // padded rows that exist from xrow0 on
 
-  int pbase[NTW];
+  sZ[tid] = 0;
+  // per position tile of this lane: unpadded row, padded row (for the epilogue), on-board mask of the 9 taps
+  int ubase[NTW], pbase[NTW], vmask[NTW];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     int p = (wp * NTW + nt) * 16 + r16;
     p = p < PT ? p : PT - 1;
     const int bl = p / HW, rem = p % HW, y = rem / H, xw = rem % H;
+    ubase[nt] = p;
     pbase[nt] = bl * PP + (y + 1) * PW + xw + 1;
+    int m = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + t / 3 - 1, xx = xw + t % 3 - 1;
+      m |= (yy >= 0 && yy < H && xx >= 0 && xx < H) ? (1 << t) : 0;
+    }
+    vmask[nt] = m;
   }
+  // DMA source offsets (elements, relative to the workgroup's first padded row / the weight slice)
+  int xoff[NXW], aoff[NAW];
+#pragma unroll
+  for (int i = 0; i < NXW; ++i) {
+    int u = (wave + 8 * i) * 16 + r16;
+    u = u < PT ? u : PT - 1;
+    const int bl = u / HW, rem = u % HW, y = rem / H, xw = rem % H;
+    int prow = bl * PP + (y + 1) * PW + xw + 1;
+    prow = prow < rows_left ? prow : rows_left - 1;
+    xoff[i] = prow * CIN + q * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < NAW; ++i) aoff[i] = ((wave + 8 * i) * 16 + r16) * CIN + q * 8;
+  const uint16_t* xwg = x + xrow0 * CIN;
+
   f32x4 acc[MTW][NTW];
 #pragma unroll
   for (int i = 0; i < MTW; ++i)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-  // DMA issue: piece j covers LDS slots [64j, 64j+64); slot e = row*4 + (chunk ^ ((row>>2)&3))
   auto dma_x = [&](int c0, int buf) {
 #pragma unroll
-    for (int i = 0; i < (XI + 7) / 8; ++i) {
+    for (int i = 0; i < NXW; ++i) {
       const int j = wave + 8 * i;
-      if (j < XI) {
-        const int e = j * 64 + lane, row = e >> 2, ch = (e & 3) ^ ((row >> 2) & 3);
-        long grow = xrow0 + row;
-        grow = grow < xrow_max ? grow : xrow_max;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + grow * CIN + c0 + ch * 8),
+      if (j < XI)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xwg + xoff[i] + c0),
                                          (__attribute__((address_space(3))) void*)(sX + (size_t)buf * XBUF + j * 512), 16, 0, 0);
-      }
     }
   };
   auto dma_a = [&](int tap, int c0, int buf) {
+    const uint16_t* wt = w + (size_t)tap * COUT * CIN + c0;
 #pragma unroll
-    for (int i = 0; i < (AI + 7) / 8; ++i) {
+    for (int i = 0; i < NAW; ++i) {
       const int j = wave + 8 * i;
-      if (j < AI) {
-        const int e = j * 64 + lane, row = e >> 2, ch = (e & 3) ^ ((row >> 2) & 3);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + ((size_t)tap * COUT + row) * CIN + c0 + ch * 8),
+      if (j < AI)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + aoff[i]),
                                          (__attribute__((address_space(3))) void*)(sA + (size_t)buf * ABUF + j * 512), 16, 0, 0);
-      }
     }
   };
 
   const int nchunk = CIN / KC, nstage = nchunk * 9;
+  const int nA = (AI - wave + 7) / 8, nX = (XI - wave + 7) / 8;   // pieces this wave issues per slice / chunk
   dma_x(0, 0); dma_a(0, 0, 0);
-  __syncthreads();
-  const int aswz = (q ^ ((r16 >> 2) & 3)) * 8;   // (row >> 2) & 3 of an A row only depends on r16
+  if (nstage > 1) dma_a(1, 0, 1);
+  wait_vmcnt(nstage > 1 ? nA : 0);
+  __syncthreads();   // also publishes the zero block
+  const int lane_off = q * 128 + r16 * 8;   // element offset of (row & 15 = r16, chunk q) inside a piece
+  int abuf = 0;
   for (int s = 0; s < nstage; ++s) {
     const int chunk = s / 9, tap = s - chunk * 9;
-    if (s + 1 < nstage) {
-      dma_a(tap == 8 ? 0 : tap + 1, (tap == 8 ? chunk + 1 : chunk) * KC, (s + 1) & 1);
-      if (tap == 8) dma_x((chunk + 1) * KC, (chunk + 1) & 1);
+    int inflight = 0;
+    if (s + 2 < nstage) {
+      const int s2 = s + 2, c2 = s2 / 9;
+      dma_a(s2 - c2 * 9, c2 * KC, abuf >= 1 ? abuf - 1 : 2);   // (s + 2) % 3
+      inflight += nA;
     }
+    if (tap == 4 && chunk + 1 < nchunk) { dma_x((chunk + 1) * KC, (chunk + 1) & 1); inflight += nX; }
     {
-      const uint16_t* A = sA + (size_t)(s & 1) * ABUF + (wc * MTW * 16 + r16) * 32 + aswz;
-      const uint16_t* X = sX + (size_t)(chunk & 1) * XBUF;
-      const int toff = (tap / 3 - 1) * PW + (tap % 3 - 1);
+      const uint16_t* A = sA + (size_t)abuf * ABUF + wc * MTW * 512 + lane_off;
+      const uint16_t* X = sX + (size_t)(chunk & 1) * XBUF + q * 128;
+      const uint16_t* Z = sZ + q * 128;
+      const int toff = (tap / 3 - 1) * H + (tap % 3 - 1);
+      auto read_b = [&](int nt) -> bf16x8 {
+        const int u = ubase[nt] + toff;
+        const uint16_t* src = ((vmask[nt] >> tap) & 1) ? X + (u >> 4) * 512 : Z;
+        return *(const bf16x8*)(src + (u & 15) * 8);
+      };
       bf16x8 a[MTW];
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) a[mt] = *(const bf16x8*)(A + mt * 16 * 32);
+      for (int mt = 0; mt < MTW; ++mt) a[mt] = *(const bf16x8*)(A + mt * 512);
+      bf16x8 bfr[NTW];
+      bfr[0] = read_b(0);
+      if (NTW > 1) bfr[1] = read_b(1);
+      // pin the order: all weight fragments + two activation fragments first, then one more
+      // activation read in front of each group of MTW MFMAs (the compiler would otherwise sink every
+      // read to just before its use and expose the LDS latency once per group)
+      __builtin_amdgcn_sched_group_barrier(0x100, MTW + (NTW > 1 ? 2 : 1), 0);
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
-        const int row = pbase[nt] + toff;
-        const bf16x8 b = *(const bf16x8*)(X + row * 32 + ((q ^ ((row >> 2) & 3)) * 8));
+        if (nt + 2 < NTW) {
+          bfr[nt + 2] = read_b(nt + 2);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < MTW; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MTW, 0);
       }
     }
-    __syncthreads();   // also retires this wave's DMA (vmcnt(0)) before anyone reads the other buffers
+    wait_vmcnt(inflight);
+    __builtin_amdgcn_s_barrier();
+    abuf = abuf == 2 ? 0 : abuf + 1;
   }
-  // epilogue: lane holds position r16 of each position tile, channels 4*q+reg of each channel tile
+  // epilogue: lane holds position r16 of each position tile, channels 4*q+reg of each channel tile.
+  // Channel tile outermost so that the bias (one float4) and the NTW residual words of a tile are
+  // all requested before the first is used (one memory latency per channel tile, not per word).
+  bool live[NTW];
+  size_t obase[NTW];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     const int p = (wp * NTW + nt) * 16 + r16;
-    const int bl = p / HW;
-    if (p >= PT || board0 + bl >= B) continue;
-    const size_t obase = (size_t)(xrow0 + pbase[nt]) * COUT;
+    live[nt] = p < PT && board0 + p / HW < B;
+    obase[nt] = (size_t)(xrow0 + pbase[nt]) * COUT;
+  }
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) {
-      const int co = (wc * MTW + mt) * 16 + q * 4;
-      float v[4];
+  for (int mt = 0; mt < MTW; ++mt) {
+    const int co = (wc * MTW + mt) * 16 + q * 4;
+    const float4 bv = *(const float4*)(bias + co);
+    uint2 rr[NTW];
+    if (res) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] + bias[co + r];
+      for (int nt = 0; nt < NTW; ++nt) rr[nt] = live[nt] ? *(const uint2*)(res + obase[nt] + co) : make_uint2(0, 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      float v[4] = {acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w};
       if (res) {
-        const uint2 rr = *(const uint2*)(res + obase + co);
-        v[0] += bf2f((uint16_t)(rr.x & 0xFFFF)); v[1] += bf2f((uint16_t)(rr.x >> 16));
-        v[2] += bf2f((uint16_t)(rr.y & 0xFFFF)); v[3] += bf2f((uint16_t)(rr.y >> 16));
+        v[0] += bf2f((uint16_t)(rr[nt].x & 0xFFFF)); v[1] += bf2f((uint16_t)(rr[nt].x >> 16));
+        v[2] += bf2f((uint16_t)(rr[nt].y & 0xFFFF)); v[3] += bf2f((uint16_t)(rr[nt].y >> 16));
       }
       if (relu) {
 #pragma unroll
@@ -260,7 +340,7 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
       uint2 o;
       o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
       o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-      *(uint2*)(out + obase + co) = o;
+      if (live[nt]) *(uint2*)(out + obase[nt] + co) = o;
     }
   }
 }
@@ -447,7 +527,7 @@ struct NetImpl {
   }
   template <int COUT, int H, int NBW>
   void launch_board(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
-    constexpr size_t smem = ((size_t)2 * (COUT * 4 / 64) * 512 + (size_t)2 * ((NBW * (H + 2) * (H + 2) * 4 + 63) / 64) * 512) * 2;
+    constexpr size_t smem = ((size_t)3 * (COUT / 16) * 512 + (size_t)2 * ((NBW * H * H + 15) / 16) * 512 + 512) * 2;
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)conv3x3_board_kernel<COUT, H, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
