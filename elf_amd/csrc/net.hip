@@ -147,27 +147,34 @@ __device__ inline void wait_vmcnt(int n) {
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
 
 // Board-tiled 3x3 convolution (the fast path for 19x19 and 8x8): one 512-thread workgroup owns NBW
-// whole boards.  For every 32-channel input chunk the activations of those boards are staged in LDS
-// ONCE and serve all nine taps, so HBM/L2 sees each activation once per layer instead of nine
-// times; the per-tap weight slices stream through a 3-deep LDS ring.
+// whole boards.  For every 32-channel input chunk the padded activations of those boards are staged
+// in LDS ONCE and serve all nine taps, so HBM/L2 sees each activation once per layer instead of
+// nine times; the per-tap weight slices stream through a 6-slot LDS ring.
 //
 // Staging is LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass).  A DMA
-// wave-instruction writes 1 KiB lane-linearly but its 64 SOURCE addresses are free, so the LDS image
-// is chosen for the reader: a 1-KiB piece holds 16 rows (positions or output channels) x 32 channels
-// as [16-byte chunk q][row & 15]; row r, chunk q lives at (r >> 4) * 1024 + q * 256 + (r & 15) * 16.
-// Every ds_read_b128 lane group then covers 16 consecutive rows = 16 distinct bank slots: conflict
-// free for the weight fragments and for the activation fragments at every tap, because the
-// activation image is the UNPADDED board (row = b*H*H + y*H + x; a tap is the constant row offset
-// dy*H + dx) and lanes whose neighbour falls off the board read a zero block at their own slot.
-//
-// Pipeline: weights two stages ahead, the next activation chunk five stages ahead (issued at tap
-// 4); DMA stays in flight across the per-stage barrier - a wave retires only what the NEXT stage
-// reads with a counted s_waitcnt vmcnt(N), then a raw s_barrier publishes it.  Activation
+// wave-instruction writes 1 KiB lane-linearly but its 64 SOURCE addresses are free, so the LDS
+// images are chosen for the reader:
+//   weights      1-KiB piece = 16 output channels x 32 input channels stored [16-B chunk q][co & 15]:
+//                a fragment read covers 16 distinct bank slots per lane group (conflict free) and
+//                the channel tile is an immediate offset;
+//   activations  padded board rows at an 80-byte stride (4 data slots + 1 unused slot per row; the
+//                DMA lanes that land on an unused slot re-fetch slot 0).  The image is LINEAR in the
+//                padded position, so a tap is a compile-time byte offset: with the nine taps
+//                unrolled an activation fragment read costs no address arithmetic at all.  (The
+//                matrix instruction holds the SIMD's vector issue for 8 of its 16 cycles; per-read
+//                swizzle arithmetic was what kept the matrix pipe at ~40 %.)
+// Pipeline: two stages (taps) per barrier; weights four stages ahead through a 6-slot ring, the next
+// activation chunk four to five stages ahead; DMA stays in flight across the barrier - a wave retires
+// only what the NEXT pair reads with a counted s_waitcnt vmcnt(N), then a raw s_barrier publishes it.  Activation
 // fragments are read two position tiles ahead of the MFMAs that consume them.
 // Wave grid 2 (output-channel halves) x 4 (position quarters); a wave keeps COUT/32 x NTW
 // accumulator tiles (16x16 fp32) in registers, so each LDS fragment read feeds 6-7 MFMAs.
@@ -180,53 +187,44 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
   constexpr int NT = (PT + 15) / 16;       // position tiles
   constexpr int NTW = (NT + 3) / 4;        // per wave
   constexpr int MTW = COUT / 32;           // output-channel tiles per wave (half of COUT)
-  constexpr int XI = NT;                   // 1-KiB DMA pieces per activation chunk
-  constexpr int AI = COUT / 16;            // ... per weight slice
-  constexpr int XBUF = XI * 512, ABUF = AI * 512;   // u16 elements per buffer
+  constexpr int XROWS = NBW * PP;          // padded rows staged per chunk
+  constexpr int XI = (XROWS * 5 + 63) / 64;   // 1-KiB DMA pieces per activation chunk (5 slots per row)
+  constexpr int AI = COUT / 16;               // ... per weight slice
+  constexpr int XBYTES = XI * 1024, ABYTES = AI * 1024;
   constexpr int NXW = (XI + 7) / 8, NAW = (AI + 7) / 8;
-  extern __shared__ __attribute__((aligned(1024))) uint16_t smem[];
-  uint16_t* sA = smem;                 // [3][ABUF]
-  uint16_t* sX = smem + 3 * ABUF;      // [2][XBUF]
-  uint16_t* sZ = sX + 2 * XBUF;        // [512] zeros
+  extern __shared__ __attribute__((aligned(1024))) char smemc[];
+  constexpr int RING = 6;
+  char* sA = smemc;                       // [RING][ABYTES]
+  char* sX = smemc + RING * ABYTES;       // [2][XBYTES]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave & 1, wp = wave >> 1;
   const int r16 = lane & 15, q = lane >> 4;
   const int board0 = blockIdx.x * NBW;
   const long xrow0 = (long)board0 * PP;
-  const int rows_left = (int)min((long)NBW * PP, (long)B * PP - xrow0);   // padded rows that exist from xrow0 on
+  const int rows_left = (int)min((long)XROWS, (long)B * PP - xrow0);   // padded rows that exist from xrow0 on
 
-  sZ[tid] = 0;
-  // per position tile of this lane: unpadded row, padded row (for the epilogue), on-board mask of the 9 taps
-  int ubase[NTW], pbase[NTW], vmask[NTW];
+  // per position tile of this lane: padded row, and the byte offset of its (dy,dx) = (-1,-1) neighbour
+  int pb[NTW];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     int p = (wp * NTW + nt) * 16 + r16;
     p = p < PT ? p : PT - 1;
     const int bl = p / HW, rem = p % HW, y = rem / H, xw = rem % H;
-    ubase[nt] = p;
-    pbase[nt] = bl * PP + (y + 1) * PW + xw + 1;
-    int m = 0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int yy = y + t / 3 - 1, xx = xw + t % 3 - 1;
-      m |= (yy >= 0 && yy < H && xx >= 0 && xx < H) ? (1 << t) : 0;
-    }
-    vmask[nt] = m;
+    pb[nt] = (bl * PP + (y + 1) * PW + xw + 1 - (PW + 1)) * 80 + q * 16;
   }
-  // DMA source offsets (elements, relative to the workgroup's first padded row / the weight slice)
-  int xoff[NXW], aoff[NAW];
+  // DMA source offsets (bytes, relative to the workgroup's first padded row / the weight slice)
+  uint32_t xoff[NXW], aoff[NAW];
 #pragma unroll
   for (int i = 0; i < NXW; ++i) {
-    int u = (wave + 8 * i) * 16 + r16;
-    u = u < PT ? u : PT - 1;
-    const int bl = u / HW, rem = u % HW, y = rem / H, xw = rem % H;
-    int prow = bl * PP + (y + 1) * PW + xw + 1;
-    prow = prow < rows_left ? prow : rows_left - 1;
-    xoff[i] = prow * CIN + q * 8;
+    const int slot = (wave + 8 * i) * 64 + lane;
+    int row = slot / 5, ch = slot - row * 5;
+    ch = ch == 4 ? 0 : ch;
+    row = row < rows_left ? row : rows_left - 1;
+    xoff[i] = (uint32_t)(row * CIN + ch * 8) * 2u;
   }
 #pragma unroll
-  for (int i = 0; i < NAW; ++i) aoff[i] = ((wave + 8 * i) * 16 + r16) * CIN + q * 8;
-  const uint16_t* xwg = x + xrow0 * CIN;
+  for (int i = 0; i < NAW; ++i) aoff[i] = (uint32_t)(((wave + 8 * i) * 16 + r16) * CIN + q * 8) * 2u;
+  const char* xwg = (const char*)(x + xrow0 * CIN);
 
   f32x4 acc[MTW][NTW];
 #pragma unroll
@@ -235,76 +233,79 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
     for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
   auto dma_x = [&](int c0, int buf) {
+    const char* src = xwg + c0 * 2;
 #pragma unroll
     for (int i = 0; i < NXW; ++i) {
       const int j = wave + 8 * i;
       if (j < XI)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xwg + xoff[i] + c0),
-                                         (__attribute__((address_space(3))) void*)(sX + (size_t)buf * XBUF + j * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + xoff[i]),
+                                         (__attribute__((address_space(3))) void*)(sX + buf * XBYTES + j * 1024), 16, 0, 0);
     }
   };
   auto dma_a = [&](int tap, int c0, int buf) {
-    const uint16_t* wt = w + (size_t)tap * COUT * CIN + c0;
+    const char* src = (const char*)(w + (size_t)tap * COUT * CIN + c0);
 #pragma unroll
     for (int i = 0; i < NAW; ++i) {
       const int j = wave + 8 * i;
       if (j < AI)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + aoff[i]),
-                                         (__attribute__((address_space(3))) void*)(sA + (size_t)buf * ABUF + j * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + aoff[i]),
+                                         (__attribute__((address_space(3))) void*)(sA + buf * ABYTES + j * 1024), 16, 0, 0);
     }
   };
 
   const int nchunk = CIN / KC, nstage = nchunk * 9;
   const int nA = (AI - wave + 7) / 8, nX = (XI - wave + 7) / 8;   // pieces this wave issues per slice / chunk
-  dma_x(0, 0); dma_a(0, 0, 0);
-  if (nstage > 1) dma_a(1, 0, 1);
-  wait_vmcnt(nstage > 1 ? nA : 0);
-  __syncthreads();   // also publishes the zero block
-  const int lane_off = q * 128 + r16 * 8;   // element offset of (row & 15 = r16, chunk q) inside a piece
-  int abuf = 0;
-  for (int s = 0; s < nstage; ++s) {
-    const int chunk = s / 9, tap = s - chunk * 9;
-    int inflight = 0;
-    if (s + 2 < nstage) {
-      const int s2 = s + 2, c2 = s2 / 9;
-      dma_a(s2 - c2 * 9, c2 * KC, abuf >= 1 ? abuf - 1 : 2);   // (s + 2) % 3
-      inflight += nA;
-    }
-    if (tap == 4 && chunk + 1 < nchunk) { dma_x((chunk + 1) * KC, (chunk + 1) & 1); inflight += nX; }
-    {
-      const uint16_t* A = sA + (size_t)abuf * ABUF + wc * MTW * 512 + lane_off;
-      const uint16_t* X = sX + (size_t)(chunk & 1) * XBUF + q * 128;
-      const uint16_t* Z = sZ + q * 128;
-      const int toff = (tap / 3 - 1) * H + (tap % 3 - 1);
-      auto read_b = [&](int nt) -> bf16x8 {
-        const int u = ubase[nt] + toff;
-        const uint16_t* src = ((vmask[nt] >> tap) & 1) ? X + (u >> 4) * 512 : Z;
-        return *(const bf16x8*)(src + (u & 15) * 8);
-      };
-      bf16x8 a[MTW];
+  // stage s = (chunk, tap) = (s / 9, s % 9); its weight slice lives in ring slot s % RING
+  auto dma_stage = [&](int s2) { const int c2 = s2 / 9; dma_a(s2 - c2 * 9, c2 * KC, s2 % RING); };
+  dma_x(0, 0);
+  for (int s2 = 0; s2 < 4 && s2 < nstage; ++s2) dma_stage(s2);
+  wait_vmcnt(nstage > 2 ? 2 * nA : 0);   // stages 0,1 (and the first chunk) have landed; 2,3 may still fly
+  __syncthreads();
+  const char* Alane = sA + wc * MTW * 1024 + q * 256 + r16 * 16;
+  // one stage = one tap x 32 input channels: MTW x NTW MFMAs per wave
+  auto compute = [&](int s) {
+    const int chunk = s / 9, tap = s - chunk * 9, ty = tap / 3;
+    const char* A = Alane + (s % RING) * ABYTES;
+    const char* X = sX + (chunk & 1) * XBYTES + (ty * PW + (tap - ty * 3)) * 80;
+    bf16x8 a[MTW];
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) a[mt] = *(const bf16x8*)(A + mt * 512);
-      bf16x8 bfr[NTW];
-      bfr[0] = read_b(0);
-      if (NTW > 1) bfr[1] = read_b(1);
-      // pin the order: all weight fragments + two activation fragments first, then one more
-      // activation read in front of each group of MTW MFMAs (the compiler would otherwise sink every
-      // read to just before its use and expose the LDS latency once per group)
-      __builtin_amdgcn_sched_group_barrier(0x100, MTW + (NTW > 1 ? 2 : 1), 0);
+    for (int mt = 0; mt < MTW; ++mt) a[mt] = *(const bf16x8*)(A + mt * 1024);
+    bf16x8 bfr[NTW];
+    bfr[0] = *(const bf16x8*)(X + pb[0]);
+    if (NTW > 1) bfr[1] = *(const bf16x8*)(X + pb[NTW > 1 ? 1 : 0]);
+    // pin the order: all weight fragments + two activation fragments first, then one more
+    // activation read in front of each group of MTW MFMAs (the compiler would otherwise sink
+    // every read to just before its use and expose the LDS latency once per group)
+    __builtin_amdgcn_sched_group_barrier(0x100, MTW + (NTW > 1 ? 2 : 1), 0);
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        if (nt + 2 < NTW) {
-          bfr[nt + 2] = read_b(nt + 2);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, MTW, 0);
+    for (int nt = 0; nt < NTW; ++nt) {
+      if (nt + 2 < NTW) {
+        bfr[nt + 2] = *(const bf16x8*)(X + pb[nt + 2 < NTW ? nt + 2 : 0]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MTW, 0);
     }
+  };
+  // Two stages per barrier.  At the top of a pair (s, s+1) the weight slices of stages s+4, s+5 are
+  // requested (ring of 6), and the next activation chunk when the pair contains tap 4; at the
+  // bottom the wave retires everything except what it requested in this pair (counted vmcnt),
+  // then a raw s_barrier publishes the pair s+2, s+3.  The loop stays rolled: stage-dependent
+  // offsets are wave-uniform scalars, an activation fragment read costs one v_add.
+#pragma unroll 1
+  for (int s = 0; s < nstage; s += 2) {
+    int inflight = 0;
+    if (s + 4 < nstage) { dma_stage(s + 4); inflight += nA; }
+    if (s + 5 < nstage) { dma_stage(s + 5); inflight += nA; }
+    {
+      const int chunk = s / 9, tap = s - chunk * 9;
+      if ((tap == 3 || tap == 4) && chunk + 1 < nchunk) { dma_x((chunk + 1) * KC, (chunk + 1) & 1); inflight += nX; }
+    }
+    compute(s);
+    if (s + 1 < nstage) compute(s + 1);
     wait_vmcnt(inflight);
     __builtin_amdgcn_s_barrier();
-    abuf = abuf == 2 ? 0 : abuf + 1;
   }
   // epilogue: lane holds position r16 of each position tile, channels 4*q+reg of each channel tile.
   // Channel tile outermost so that the bias (one float4) and the NTW residual words of a tile are
@@ -315,17 +316,30 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
   for (int nt = 0; nt < NTW; ++nt) {
     const int p = (wp * NTW + nt) * 16 + r16;
     live[nt] = p < PT && board0 + p / HW < B;
-    obase[nt] = (size_t)(xrow0 + pbase[nt]) * COUT;
+    obase[nt] = (size_t)(xrow0 + (pb[nt] - q * 16) / 80 + (PW + 1)) * COUT;
   }
-#pragma unroll
-  for (int mt = 0; mt < MTW; ++mt) {
+  // Software-pipelined over the channel tiles: the bias and residual words of tile mt+1 are requested
+  // BEFORE the stores of tile mt are issued.  vmcnt retires in order, so a load issued after stores
+  // could only be consumed once those stores had completed (a full HBM write round trip per tile).
+  auto load_tile = [&](int mt, float4& bv, uint2 (&rr)[NTW]) {
     const int co = (wc * MTW + mt) * 16 + q * 4;
-    const float4 bv = *(const float4*)(bias + co);
-    uint2 rr[NTW];
+    bv = *(const float4*)(bias + co);
     if (res) {
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) rr[nt] = live[nt] ? *(const uint2*)(res + obase[nt] + co) : make_uint2(0, 0);
     }
+  };
+  float4 bv_next; uint2 rr_next[NTW];
+  load_tile(0, bv_next, rr_next);
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) {
+    const int co = (wc * MTW + mt) * 16 + q * 4;
+    const float4 bv = bv_next;
+    uint2 rr[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) rr[nt] = rr_next[nt];
+    if (mt + 1 < MTW) load_tile(mt + 1, bv_next, rr_next);
+    uint2 o[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
       float v[4] = {acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w};
@@ -337,10 +351,24 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
-      uint2 o;
-      o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-      o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-      if (live[nt]) *(uint2*)(out + obase[nt] + co) = o;
+      o[nt].x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+      o[nt].y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    }
+    // Stores are issue-bound, so make them 16 bytes wide: lanes q and q+1 (16 lanes apart) hold
+    // adjacent 4-channel groups.  v_permlane16_swap exchanges the odd 16-lane rows of one register
+    // with the even rows of another; applied to the words of a PAIR of position tiles it leaves
+    // rows 0/2 with channels [8(q/2), 8(q/2)+8) of the first tile and rows 1/3 with those of the second.
+#pragma unroll
+    for (int nt = 0; nt + 1 < NTW; nt += 2) {
+      const auto sx = __builtin_amdgcn_permlane16_swap(o[nt].x, o[nt + 1].x, false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(o[nt].y, o[nt + 1].y, false, false);
+      const bool second = q & 1;
+      const uint4 st = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      const size_t ob = second ? obase[nt + 1] : obase[nt];
+      if (second ? live[nt + 1] : live[nt]) *(uint4*)(out + ob + (wc * MTW + mt) * 16 + (q >> 1) * 8) = st;
+    }
+    if (NTW & 1) {
+      if (live[NTW - 1]) *(uint2*)(out + obase[NTW - 1] + co) = o[NTW - 1];
     }
   }
 }
@@ -527,7 +555,7 @@ struct NetImpl {
   }
   template <int COUT, int H, int NBW>
   void launch_board(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
-    constexpr size_t smem = ((size_t)3 * (COUT / 16) * 512 + (size_t)2 * ((NBW * H * H + 15) / 16) * 512 + 512) * 2;
+    constexpr size_t smem = (size_t)6 * (COUT / 16) * 1024 + (size_t)2 * ((NBW * (H + 2) * (H + 2) * 5 + 63) / 64) * 1024;
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)conv3x3_board_kernel<COUT, H, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
