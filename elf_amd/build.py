@@ -36,7 +36,38 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    build_pybind(force=force or bool(procs), verbose=verbose)
     return LIB
+
+
+# Python-visible facade modules with the reference's module names (host C++ only, g++):
+# _elf and one _elfgames_<game> per game that has search kernels.
+PYB = os.path.join(HERE, "pybind")
+GAME_MODULES = {"_elfgames_american_checkers": 0}
+
+
+def build_pybind(force=False, verbose=False):
+    import sysconfig
+    import pybind11
+    suffix = sysconfig.get_config_var("EXT_SUFFIX")
+    inc = ["-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], "-I/opt/rocm/include"]
+    base = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__", "-Wall"] + inc
+    link = ["-L" + HERE, "-lelfhip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+    hdrs = [os.path.join(PYB, "facade.h"), os.path.join(HERE, "..", "include", "elfhip.h")]
+    jobs = [("_elf", os.path.join(PYB, "elf_module.cc"), [], [])]
+    for name, gid in GAME_MODULES.items():
+        jobs.append((name, os.path.join(PYB, "game_module.cc"), ["-DELFGAME_MODULE=" + name, "-DELFGAME_ID=%d" % gid], link))
+    procs = []
+    for name, src, defs, lk in jobs:
+        out = os.path.join(PYB, name + suffix)
+        if force or _newer(src, out) or any(_newer(h, out) for h in hdrs):
+            cmd = base + defs + [src, "-o", out] + lk
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((name, subprocess.Popen(cmd)))
+    for name, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("g++ failed on pybind module %s" % name)
 
 
 if __name__ == "__main__":

@@ -9,6 +9,37 @@
 
 static thread_local char g_err[512] = "";
 
+namespace {
+// row gather / scatter used by the batch collector: dst[i] = src[index[i]] (gather) or
+// dst[index[i]] = src[i] (scatter); rows are row_words u32 each, one workgroup per row.
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) rows_copy_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                        const int32_t* __restrict__ index, int row_words) {
+  const size_t i = blockIdx.x, j = (size_t)index[blockIdx.x];
+  const uint32_t* s = src + (SCATTER ? i : j) * (size_t)row_words;
+  uint32_t* d = dst + (SCATTER ? j : i) * (size_t)row_words;
+  for (int w = threadIdx.x; w < row_words; w += blockDim.x) d[w] = s[w];
+}
+int rows_copy(bool scatter, const void* d_src, long long row_bytes, const int32_t* d_index, int n_rows, void* d_dst,
+              int device, void* hip_stream) {
+  if (!d_src || !d_dst || !d_index || row_bytes <= 0 || (row_bytes & 3) || n_rows < 0) {
+    elfhip_set_error("rows copy: bad arguments (row_bytes=%lld must be a positive multiple of 4, n_rows=%d)", row_bytes, n_rows);
+    return ELFHIP_EINVAL;
+  }
+  if (n_rows == 0) return ELFHIP_OK;
+  HIPCHECK(hipSetDevice(device));
+  const int rw = (int)(row_bytes / 4);
+  if (scatter)
+    hipLaunchKernelGGL(rows_copy_kernel<true>, dim3(n_rows), dim3(256), 0, (hipStream_t)hip_stream, (const uint32_t*)d_src,
+                       (uint32_t*)d_dst, d_index, rw);
+  else
+    hipLaunchKernelGGL(rows_copy_kernel<false>, dim3(n_rows), dim3(256), 0, (hipStream_t)hip_stream, (const uint32_t*)d_src,
+                       (uint32_t*)d_dst, d_index, rw);
+  HIPCHECK(hipGetLastError());
+  return ELFHIP_OK;
+}
+}  // namespace
+
 void elfhip_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -150,6 +181,15 @@ int elfhip_boards_playout(elfhip_boards* b, int nply, uint64_t seed, uint64_t fi
   if (nply < 0 || nply > (1 << 20)) { elfhip_set_error("boards_playout: nply=%d out of range", nply); return ELFHIP_EINVAL; }
   if (nply == 0) return ELFHIP_OK;
   return b->slab->playout(nply, seed, first_board_id, d_moves);
+}
+
+int elfhip_gather_rows(const void* d_src, long long row_bytes, const int32_t* d_index, int n_rows, void* d_dst, int device,
+                       void* hip_stream) {
+  return rows_copy(false, d_src, row_bytes, d_index, n_rows, d_dst, device, hip_stream);
+}
+int elfhip_scatter_rows(const void* d_src, long long row_bytes, const int32_t* d_index, int n_rows, void* d_dst, int device,
+                        void* hip_stream) {
+  return rows_copy(true, d_src, row_bytes, d_index, n_rows, d_dst, device, hip_stream);
 }
 
 int elfhip_test_sort_order(int n, const float* h_keys, uint16_t* h_order) {

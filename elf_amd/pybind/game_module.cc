@@ -1,0 +1,542 @@
+// Python module `_elfgames_<game>`: GameContext / ContextOptions / GameOptions / DistriClient /
+// GameStats / WinRateStats / ClientGameSelfPlay with the names and methods of the reference's
+// module (src_cpp/elfgames/american_checkers/pybind/Pybind.cc:18-65), driving the device-resident
+// self-play engine through the C-ABI of include/elfhip.h.  Built once per game:
+//   -DELFGAME_MODULE=_elfgames_american_checkers -DELFGAME_ID=0
+//
+// What the engine does per move of ALL games (ClientGameSelfPlay::act, common/ClientGameSelfPlay.cc:
+// 249-375, which the reference runs on one thread per game):
+//   set roots -> [select a batch of leaves -> hand the rows that need the network to Python in
+//   chunks of <= batchsize ("actor_black" / "actor_white" batches) -> backup] x rollouts
+//   -> pick move / diverse move / record policy + value -> forward -> treeAdvance
+//   -> finished games: final value, win statistics, record, tree reset, restart, one "game_end"
+//      batch per finished game (GameNotifier::OnGameEnd, common/DistriClient.h:285-298).
+// Control plane (ZMQ dispatcher, model-version requests from a server) is out of scope: games start
+// with start(); DistriClient.setRequest only chooses one model (white_ver < 0) or two.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <hip/hip_runtime_api.h>
+
+#include <array>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/elfhip.h"
+#include "facade.h"
+
+#ifndef ELFGAME_MODULE
+#error "define ELFGAME_MODULE and ELFGAME_ID"
+#endif
+
+namespace py = pybind11;
+using namespace elfhip_py;
+
+namespace elfhip_gamemod {
+
+static void ck(int rc, const char* what) {
+  if (rc < 0) throw std::runtime_error(std::string(what) + ": " + elfhip_last_error());
+}
+static void hk(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// exported state words that hold side-to-move (bit 0) and ply (include/elfhip.h, oracle/*.h)
+struct MetaWord { int word, ply_shift, ply_bits; };
+static MetaWord meta_word(int game) {
+  switch (game) {
+    case ELFHIP_AMERICAN: return {4, 8, 16};
+    case ELFHIP_RUSSIAN: return {4, 8, 16};
+    case ELFHIP_UGOLKI: return {3, 8, 16};
+    default: return {20, 16, 16};
+  }
+}
+
+struct ContextOptions {  // elf/legacy/python_options_utils_cpp.h:19-50
+  int num_games = 1;
+  int batchsize = 0;
+  int T = 1;
+  std::string job_id;
+  TSOptions mcts_options;
+  void print() const {
+    py::print("JobId:", job_id, "#Game:", num_games, "T:", T, "rollouts/thread:", mcts_options.num_rollouts_per_thread,
+              "rollouts/batch:", mcts_options.num_rollouts_per_batch, "threads:", mcts_options.num_threads);
+  }
+};
+
+struct GameOptions {  // elfgames/<game>/game/GameOptions.h:11-91 (field names are the contract with game.py:237-332)
+  unsigned int seed = 0;
+  int checkers_num_future_actions = 0;
+  int human_plays_for = 0;
+  int num_games_per_thread = -1;
+  std::string mode;
+  bool use_mcts = false, use_mcts_ai2 = false;
+  bool black_use_policy_network_only = false, white_use_policy_network_only = false;
+  int policy_distri_cutoff = 20;
+  bool policy_distri_training_for_all = false;
+  int num_reset_ranking = 5000;
+  int q_min_size = 10, q_max_size = 1000, num_reader = 50;
+  float white_puct = -1.0f;
+  int white_mcts_rollout_per_batch = -1, white_mcts_rollout_per_thread = -1;
+  int eval_num_games = 400;
+  float eval_thres = 0.55f;
+  int client_max_delay_sec = 1200;
+  int selfplay_init_num = 5000, selfplay_update_num = 1000;
+  bool selfplay_async = false;
+  bool cheat_eval_new_model_wins_half = false, cheat_selfplay_random_result = false;
+  bool keep_prev_selfplay = false;
+  int eval_num_threads = 1, expected_num_clients = -1;
+  std::vector<std::string> list_files;
+  std::string server_addr, server_id;
+  int port = 0;
+  bool verbose = false;
+  std::string dump_record_prefix, selfplay_records_directory, eval_records_directory, records_buffer_directory;
+  std::string time_signature;
+  std::string info() const {
+    return "mode: " + mode + "\npolicy_distri_cutoff: " + std::to_string(policy_distri_cutoff) + "\nseed: " +
+           std::to_string(seed) + "\n";
+  }
+};
+
+struct WinRateStats {  // common/GameStats.h:22-50
+  uint64_t black_wins = 0, white_wins = 0, both_lost = 0;
+  float sum_reward = 0.0f;
+  uint64_t total_games = 0;
+};
+struct GameStats {
+  WinRateStats w;
+  WinRateStats getWinRateStats() const { return w; }
+};
+
+struct GameRecord {  // what GuardedRecords keeps per finished game (game/Record.h:87-190), as arrays
+  int game_idx = 0;
+  long long seq = 0;
+  float reward = 0;
+  std::vector<int16_t> moves;
+  std::vector<float> values;
+  std::vector<std::vector<uint8_t>> policies;
+};
+
+class SelfPlayEngine;
+
+struct DistriClient {  // common/DistriClient.h:322-403 (only what selfplay.py touches)
+  SelfPlayEngine* eng = nullptr;
+  GameStats stats;
+  long long black_ver = -1, white_ver = -1;
+  void setRequest(long long black, long long white, int num_threads);
+  GameStats& getGameStats() { return stats; }
+};
+
+struct ClientGameSelfPlay {  // common/ClientGameSelfPlay.h (console / GUI accessors)
+  SelfPlayEngine* eng = nullptr;
+  int idx = 0;
+  int getCurrentPlayer() const;
+  std::vector<int> getValidMoves() const;
+  std::vector<uint64_t> getStateWords() const;
+};
+
+class SelfPlayEngine : public elfhip_py::Engine {
+ public:
+  SelfPlayEngine(int game, const ContextOptions& co, const GameOptions& go) : game_(game), co_(co), go_(go) {
+    ck(elfhip_game_get_info(game, &gi_), "game_get_info");
+    if (go.mode != "selfplay" && go.mode != "play" && !go.mode.empty())
+      throw std::range_error("GameContext: mode '" + go.mode + "' is not built (self-play hot path only: selfplay)");
+    if (co.num_games <= 0) throw std::range_error("GameContext: num_games must be positive");
+    const char* dv = std::getenv("ELFHIP_DEVICE");
+    device_ = dv ? std::atoi(dv) : 0;
+    client_.eng = this;
+    games_.resize(co.num_games);
+    for (int i = 0; i < co.num_games; ++i) { games_[i].eng = this; games_[i].idx = i; }
+  }
+  ~SelfPlayEngine() override { release(); }
+
+  std::map<std::string, int> getParams() const {  // common/GameFeature.h:225-232
+    return {{"checkers_num_action", gi_.num_actions}, {"checkers_board_size", gi_.board_size},
+            {"checkers_num_future_actions", 1}, {"checkers_num_planes", gi_.num_planes}};
+  }
+
+  void describe_key(const std::string& key, FuncMapBase* f) const override {  // GameFeature.h:166-222
+    auto set = [&](const char* tn, int ts, std::vector<int> ext) { f->type_name = tn; f->type_size = ts; f->sz.v = ext; };
+    const int S = gi_.board_size;
+    if (key == "s") set("float", 4, {gi_.num_planes, S, S});
+    else if (key == "pi" || key == "mcts_scores") set("float", 4, {gi_.num_actions});
+    else if (key == "V" || key == "winner" || key == "checkers_predicted_value") set("float", 4, {});
+    else if (key == "a" || key == "rv" || key == "black_ver" || key == "white_ver" || key == "selfplay_ver") set("int64_t", 8, {});
+    else if (key == "offline_a") set("int64_t", 8, {go_.checkers_num_future_actions});
+    else if (key == "game_idx" || key == "move_idx" || key == "checkers_aug_code" || key == "checkers_num_move") set("int32_t", 4, {});
+    else throw std::out_of_range("allocateSharedMem: unknown batch key '" + key + "'");
+  }
+
+  void on_allocate(SharedMem* m) override { by_label_[m->opts.label].push_back(m); }
+
+  void start() override {
+    if (by_label_.find("actor_black") == by_label_.end())
+      throw std::runtime_error("GameContext: no 'actor_black' batch was allocated (game.py:383-397)");
+    const TSOptions& t = co_.mcts_options;
+    if (t.root_epsilon != 0.0f) throw std::range_error("GameContext: root_epsilon != 0 is not built");
+    if (t.pick_method != "most_visited" && t.pick_method != "strongest_prior")
+      throw std::range_error("MCTS Pick method unknown! " + t.pick_method);  // tree_search.h:615
+    hk(hipSetDevice(device_), "hipSetDevice");
+    n_ = co_.num_games;
+    B_ = t.num_rollouts_per_batch;
+    // search threads are serialised: num_threads x num_rollouts_per_thread rollouts on one "thread"
+    // (the reference's result is only defined run-to-run for num_threads == 1)
+    R_ = t.num_rollouts_per_thread * (t.num_threads > 0 ? t.num_threads : 1);
+    elfhip_ts_options o{R_, B_, t.virtual_loss, t.alg_opt.use_prior ? 1 : 0, t.alg_opt.c_puct,
+                        t.alg_opt.unexplored_q_zero ? 1 : 0, t.alg_opt.root_unexplored_q_zero ? 1 : 0,
+                        t.persistent_tree ? 1 : 0, t.pick_method == "most_visited" ? 0 : 1, 0, 0};
+    ck(elfhip_boards_create(game_, n_, device_, &boards_), "boards_create");
+    ck(elfhip_mcts_create(game_, n_, &o, device_, &mcts_), "mcts_create");
+    const size_t slots = (size_t)n_ * B_, A = gi_.num_actions;
+    feat_row_ = (size_t)gi_.num_planes * gi_.board_size * gi_.board_size * 4;
+    max_chunk_ = 1;
+    for (auto& kv : by_label_) for (auto* m : kv.second) max_chunk_ = std::max(max_chunk_, m->opts.batchsize);
+    dmalloc(&d_feat_, slots * feat_row_); dmalloc(&d_need_, slots); dmalloc(&d_pi_, slots * A * 4); dmalloc(&d_v_, slots * 4);
+    dmalloc(&d_idx_, slots * 4); dmalloc(&d_cfeat_, (size_t)max_chunk_ * feat_row_); dmalloc(&d_cpi_, (size_t)max_chunk_ * A * 4);
+    dmalloc(&d_cv_, (size_t)max_chunk_ * 4);
+    dmalloc(&d_move_, (size_t)n_ * 2); dmalloc(&d_pol_, (size_t)n_ * A); dmalloc(&d_val_, (size_t)n_ * 4);
+    dmalloc(&d_ply_, (size_t)n_ * 4); dmalloc(&d_ok_, (size_t)n_); dmalloc(&d_term_, (size_t)n_);
+    dmalloc(&d_mask_, (size_t)n_ * gi_.mask_words * 8); dmalloc(&d_reward_, (size_t)n_ * 4);
+    hk(hipMemset(d_pi_, 0, slots * A * 4), "memset"); hk(hipMemset(d_v_, 0, slots * 4), "memset");
+    h_need_.resize(slots); h_states_.resize((size_t)n_ * gi_.state_words); h_ply_.assign(n_, 1); h_player_.assign(n_, 0);
+    h_move_.resize(n_); h_val_.resize(n_); h_pol_.resize((size_t)n_ * A); h_ok_.resize(n_); h_term_.resize(n_); h_reward_.resize(n_);
+    h_cv_.resize(max_chunk_); h_cpi_.resize((size_t)max_chunk_ * A);
+    cur_.assign(n_, GameRecord()); seq_.assign(n_, 0);
+    refresh_states();
+    phase_ = BEGIN;
+    running_ = true;
+  }
+
+  SharedMem* next_batch() override {
+    if (!running_) return nullptr;
+    hk(hipSetDevice(device_), "hipSetDevice");
+    for (;;) {
+      if (!out_.empty()) { SharedMem* m = out_.front(); out_.pop_front(); return m; }
+      switch (phase_) {
+        case BEGIN:
+          ck(elfhip_mcts_set_roots(mcts_, boards_, nullptr), "mcts_set_roots");
+          rollouts_ = 0;
+          phase_ = SELECT;
+          break;
+        case SELECT: {
+          if (rollouts_ >= R_) { phase_ = MOVE; break; }
+          ck(elfhip_mcts_select(mcts_, nullptr, (float*)d_feat_, (uint8_t*)d_need_), "mcts_select");
+          hk(hipMemcpy(h_need_.data(), d_need_, h_need_.size(), hipMemcpyDeviceToHost), "copy need");
+          // leaves that go to the network, split by which AI owns the tree's root
+          // (curr_ai = white && _ai2 ? _ai2 : _ai1, ClientGameSelfPlay.cc:344-346)
+          pend_[0].clear(); pend_[1].clear();
+          for (size_t s = 0; s < h_need_.size(); ++s)
+            if (h_need_[s]) pend_[(two_models() && h_player_[s / B_] == 1) ? 1 : 0].push_back((int32_t)s);
+          h_idx_.clear();
+          h_idx_.insert(h_idx_.end(), pend_[0].begin(), pend_[0].end());
+          h_idx_.insert(h_idx_.end(), pend_[1].begin(), pend_[1].end());
+          if (!h_idx_.empty()) hk(hipMemcpy(d_idx_, h_idx_.data(), h_idx_.size() * 4, hipMemcpyHostToDevice), "copy idx");
+          cursor_ = 0;
+          phase_ = h_idx_.empty() ? BACKUP : SERVE;
+          break;
+        }
+        case SERVE: return serve_chunk();
+        case BACKUP:
+          ck(elfhip_mcts_backup(mcts_, (const float*)d_pi_, (const float*)d_v_), "mcts_backup");
+          rollouts_ += B_;
+          phase_ = SELECT;
+          break;
+        case MOVE:
+          make_moves();
+          phase_ = BEGIN;
+          break;
+      }
+    }
+  }
+
+  void reply(SharedMem* m, bool success) override {
+    if (m != serving_) return;  // game_end and other reply-less batches
+    serving_ = nullptr;
+    hk(hipSetDevice(device_), "hipSetDevice");
+    const int k = chunk_n_;
+    const size_t A = gi_.num_actions;
+    AnyP* pi = m->get("pi");
+    AnyP* v = m->get("V");
+    if (success && pi && v) {
+      // ReplyPolicy / ReplyValue (common/GameFeature.h:40-62): rows [0,k) of the caller's tensors
+      hk(hipMemcpy2D(d_cpi_, A * 4, pi->row(0), (size_t)pi->strides.at(0), A * 4, k, hipMemcpyHostToDevice), "copy pi");
+      hk(hipMemcpy2D(d_cv_, 4, v->row(0), (size_t)v->strides.at(0), 4, k, hipMemcpyHostToDevice), "copy V");
+    } else {  // step(FAILED): "act unsuccessful", the leaf keeps an empty policy (MCTSGameActor.h:122-124)
+      hk(hipMemset(d_cpi_, 0, (size_t)k * A * 4), "memset");
+      hk(hipMemset(d_cv_, 0, (size_t)k * 4), "memset");
+    }
+    const int32_t* idx = (const int32_t*)d_idx_ + cursor_;
+    ck(elfhip_scatter_rows(d_cpi_, (long long)A * 4, idx, k, d_pi_, device_, nullptr), "scatter pi");
+    ck(elfhip_scatter_rows(d_cv_, 4, idx, k, d_v_, device_, nullptr), "scatter V");
+    cursor_ += k;
+    if (cursor_ >= h_idx_.size()) phase_ = BACKUP;
+  }
+
+  void stop() override { running_ = false; release(); }
+
+  // ---- accessors used by the Python-visible helper objects ----
+  DistriClient* client() { return &client_; }
+  ClientGameSelfPlay* game(int i) {
+    if (i < 0 || i >= (int)games_.size()) throw std::out_of_range("getGame: index out of range");
+    return &games_[i];
+  }
+  int player_of(int i) const { return h_player_.at(i); }
+  std::vector<uint64_t> state_of(int i) const {
+    auto b = h_states_.begin() + (size_t)i * gi_.state_words;
+    return std::vector<uint64_t>(b, b + gi_.state_words);
+  }
+  std::vector<int> valid_moves_of(int i) {
+    need_running();
+    ck(elfhip_boards_legal_mask(boards_, (uint64_t*)d_mask_, nullptr), "legal_mask");
+    std::vector<uint64_t> m((size_t)n_ * gi_.mask_words);
+    hk(hipMemcpy(m.data(), d_mask_, m.size() * 8, hipMemcpyDeviceToHost), "copy mask");
+    std::vector<int> out(gi_.num_actions);
+    for (int a = 0; a < gi_.num_actions; ++a) out[a] = (int)((m[(size_t)i * gi_.mask_words + a / 64] >> (a % 64)) & 1);
+    return out;
+  }
+  py::list take_records() {
+    py::list l;
+    for (auto& r : records_) {
+      py::dict d;
+      d["game_idx"] = r.game_idx; d["seq"] = r.seq; d["reward"] = r.reward; d["moves"] = r.moves; d["values"] = r.values;
+      py::list pl;
+      for (auto& p : r.policies) pl.append(py::bytes((const char*)p.data(), p.size()));
+      d["policies"] = pl;
+      l.append(d);
+    }
+    records_.clear();
+    return l;
+  }
+  py::dict search_stats() {
+    need_running();
+    unsigned long long st[4];
+    ck(elfhip_mcts_stats(mcts_, st, nullptr), "mcts_stats");
+    py::dict d;
+    d["rollouts"] = st[0]; d["evals"] = st[1]; d["depth_sum"] = st[2]; d["edge_sum"] = st[3];
+    return d;
+  }
+  bool two_models() const { return client_.white_ver >= 0 && by_label_.count("actor_white"); }
+
+ private:
+  enum Phase { BEGIN, SELECT, SERVE, BACKUP, MOVE };
+
+  void need_running() const { if (!running_) throw std::runtime_error("GameContext: context is not running"); }
+  void dmalloc(void** p, size_t bytes) {
+    hk(hipMalloc(p, bytes ? bytes : 4), "hipMalloc");
+    allocs_.push_back(*p);
+  }
+  void release() {
+    if (mcts_) { elfhip_mcts_destroy(mcts_); mcts_ = nullptr; }
+    if (boards_) { elfhip_boards_destroy(boards_); boards_ = nullptr; }
+    for (void* p : allocs_) (void)hipFree(p);
+    allocs_.clear();
+  }
+
+  SharedMem* pick_smem(const std::string& label) {  // num_recv buffers per label are used in turn (game.py:428)
+    auto& v = by_label_.at(label);
+    SharedMem* m = v[rr_[label] % v.size()];
+    rr_[label] += 1;
+    return m;
+  }
+
+  SharedMem* serve_chunk() {
+    const bool white = cursor_ >= pend_[0].size();
+    const size_t end = white ? h_idx_.size() : pend_[0].size();
+    SharedMem* m = pick_smem(white ? "actor_white" : "actor_black");
+    const int k = (int)std::min<size_t>((size_t)m->opts.batchsize, end - cursor_);
+    const int32_t* idx = (const int32_t*)d_idx_ + cursor_;
+    if (AnyP* s = m->get("s")) {
+      // extractGameState -> BoardFeature::extract (GameFeature.h:28-32): leaf planes, one row per state
+      ck(elfhip_gather_rows(d_feat_, (long long)feat_row_, idx, k, d_cfeat_, device_, nullptr), "gather s");
+      hk(hipMemcpy2D(s->row(0), (size_t)s->strides.at(0), d_cfeat_, feat_row_, feat_row_, k, hipMemcpyDeviceToHost), "copy s");
+    }
+    if (AnyP* g = m->get("game_idx"))
+      for (int i = 0; i < k; ++i) *(int32_t*)g->row(i) = h_idx_[cursor_ + i] / B_;
+    m->effective_batchsize = k;
+    chunk_n_ = k;
+    serving_ = m;
+    return m;
+  }
+
+  void refresh_states() {
+    ck(elfhip_boards_export(boards_, h_states_.data()), "boards_export");
+    const MetaWord mw = meta_word(game_);
+    for (int i = 0; i < n_; ++i) {
+      const uint64_t w = h_states_[(size_t)i * gi_.state_words + mw.word];
+      h_player_[i] = (int)(w & 1);
+      h_ply_[i] = (int32_t)((w >> mw.ply_shift) & ((1u << mw.ply_bits) - 1));
+    }
+  }
+
+  void make_moves() {
+    const size_t A = gi_.num_actions;
+    const std::vector<int32_t> pre_ply = h_ply_;  // getPly() at the time of the move decides "diverse"
+    hk(hipMemcpy(d_ply_, h_ply_.data(), (size_t)n_ * 4, hipMemcpyHostToDevice), "copy ply");
+    // chooseAction + mcts_make_diverse_move + getValue (ClientGameSelfPlay.cc:94-122)
+    ck(elfhip_mcts_pick_moves(mcts_, (const int32_t*)d_ply_, go_.policy_distri_cutoff, go_.seed, move_counter_++,
+                              (int16_t*)d_move_, (uint8_t*)d_pol_, (float*)d_val_), "mcts_pick_moves");
+    ck(elfhip_boards_step(boards_, (const int16_t*)d_move_, (uint8_t*)d_ok_), "boards_step");
+    ck(elfhip_mcts_advance(mcts_, (const int16_t*)d_move_), "mcts_advance");
+    ck(elfhip_boards_legal_mask(boards_, (uint64_t*)d_mask_, (uint8_t*)d_term_), "legal_mask");
+    ck(elfhip_boards_evaluate(boards_, (float*)d_reward_), "boards_evaluate");
+    hk(hipMemcpy(h_move_.data(), d_move_, (size_t)n_ * 2, hipMemcpyDeviceToHost), "copy");
+    hk(hipMemcpy(h_val_.data(), d_val_, (size_t)n_ * 4, hipMemcpyDeviceToHost), "copy");
+    hk(hipMemcpy(h_pol_.data(), d_pol_, (size_t)n_ * A, hipMemcpyDeviceToHost), "copy");
+    hk(hipMemcpy(h_ok_.data(), d_ok_, (size_t)n_, hipMemcpyDeviceToHost), "copy");
+    hk(hipMemcpy(h_term_.data(), d_term_, (size_t)n_, hipMemcpyDeviceToHost), "copy");
+    hk(hipMemcpy(h_reward_.data(), d_reward_, (size_t)n_ * 4, hipMemcpyDeviceToHost), "copy");
+    refresh_states();  // ply and side to move AFTER the move (finished games still show their final state)
+    int nfin = 0;
+    for (int i = 0; i < n_; ++i) {
+      if (!h_ok_[i]) continue;  // "Something is wrong! Move cannot be applied": the reference logs and goes on
+      const bool diverse = pre_ply[i] <= go_.policy_distri_cutoff;
+      cur_[i].moves.push_back(h_move_[i]);
+      cur_[i].values.push_back(h_val_[i]);
+      if (go_.policy_distri_training_for_all || diverse)
+        cur_[i].policies.emplace_back(h_pol_.begin() + (size_t)i * A, h_pol_.begin() + (size_t)(i + 1) * A);
+      if (h_term_[i]) ++nfin;
+    }
+    if (nfin) {
+      for (int i = 0; i < n_; ++i) {
+        if (!h_term_[i]) continue;
+        // GameNotifier::OnGameEnd (DistriClient.h:285-298): MAX_STEP counts as "both lost"
+        WinRateStats& w = client_.stats.w;
+        const float r = h_reward_[i];
+        if (h_ply_[i] >= gi_.max_ply) w.both_lost++; else if (r > 0) w.black_wins++; else w.white_wins++;
+        w.sum_reward += r; w.total_games++;
+        cur_[i].game_idx = i; cur_[i].seq = seq_[i]++; cur_[i].reward = r;
+        records_.push_back(std::move(cur_[i]));
+        cur_[i] = GameRecord();
+        if (by_label_.count("game_end")) {
+          SharedMem* m = pick_smem("game_end");
+          m->effective_batchsize = 1;
+          out_.push_back(m);
+        }
+      }
+      ck(elfhip_mcts_clear(mcts_, (const uint8_t*)d_term_), "mcts_clear");            // ai->endGame -> resetTree
+      ck(elfhip_boards_reset_mask(boards_, (const uint8_t*)d_term_), "boards_reset");  // GameStateExt::restart
+      refresh_states();
+    }
+  }
+
+  int game_;
+  ContextOptions co_;
+  GameOptions go_;
+  elfhip_game_info gi_{};
+  int device_ = 0, n_ = 0, B_ = 1, R_ = 1, max_chunk_ = 1;
+  size_t feat_row_ = 0;
+  elfhip_boards* boards_ = nullptr;
+  elfhip_mcts* mcts_ = nullptr;
+  std::map<std::string, std::vector<SharedMem*>> by_label_;
+  std::map<std::string, size_t> rr_;
+  std::deque<SharedMem*> out_;
+  std::vector<void*> allocs_;
+  void *d_feat_ = nullptr, *d_need_ = nullptr, *d_pi_ = nullptr, *d_v_ = nullptr, *d_idx_ = nullptr, *d_cfeat_ = nullptr,
+       *d_cpi_ = nullptr, *d_cv_ = nullptr, *d_move_ = nullptr, *d_pol_ = nullptr, *d_val_ = nullptr, *d_ply_ = nullptr,
+       *d_ok_ = nullptr, *d_term_ = nullptr, *d_mask_ = nullptr, *d_reward_ = nullptr;
+  std::vector<uint8_t> h_need_, h_pol_, h_ok_, h_term_;
+  std::vector<uint64_t> h_states_;
+  std::vector<int32_t> h_ply_, h_idx_, pend_[2];
+  std::vector<int> h_player_;
+  std::vector<int16_t> h_move_;
+  std::vector<float> h_val_, h_reward_, h_cv_, h_cpi_;
+  std::vector<GameRecord> cur_;
+  std::vector<long long> seq_;
+  std::deque<GameRecord> records_;
+  Phase phase_ = BEGIN;
+  int rollouts_ = 0, chunk_n_ = 0;
+  size_t cursor_ = 0;
+  uint64_t move_counter_ = 0;
+  SharedMem* serving_ = nullptr;
+  bool running_ = false;
+  DistriClient client_;
+  std::vector<ClientGameSelfPlay> games_;
+};
+
+void DistriClient::setRequest(long long black, long long white, int) { black_ver = black; white_ver = white; }
+int ClientGameSelfPlay::getCurrentPlayer() const { return eng->player_of(idx); }
+std::vector<int> ClientGameSelfPlay::getValidMoves() const { return eng->valid_moves_of(idx); }
+std::vector<uint64_t> ClientGameSelfPlay::getStateWords() const { return eng->state_of(idx); }
+
+class GameContext {  // elfgames/<game>/train/GameContext.h:46-160
+ public:
+  GameContext(const ContextOptions& co, const GameOptions& go) : eng_(new SelfPlayEngine(ELFGAME_ID, co, go)), ctx_(new Context(eng_.get())) {}
+  Context* ctx() { return ctx_.get(); }
+  std::map<std::string, int> getParams() const { return eng_->getParams(); }
+  ClientGameSelfPlay* getGame(int i) { return eng_->game(i); }
+  DistriClient* getClient() { return eng_->client(); }
+  py::object getServer() { return py::none(); }  // training side: out of scope
+  py::list takeRecords() { return eng_->take_records(); }
+  py::dict searchStats() { return eng_->search_stats(); }
+
+ private:
+  std::unique_ptr<SelfPlayEngine> eng_;
+  std::unique_ptr<Context> ctx_;
+};
+
+}  // namespace elfhip_gamemod
+
+using namespace elfhip_gamemod;
+
+PYBIND11_MODULE(ELFGAME_MODULE, m) {
+  py::module_::import("_elf");  // Context / SharedMem / TSOptions types live there, as in the reference
+  auto ref = py::return_value_policy::reference_internal;
+
+  py::class_<GameContext>(m, "GameContext")
+      .def(py::init<const ContextOptions&, const GameOptions&>())
+      .def("ctx", &GameContext::ctx, ref)
+      .def("getParams", &GameContext::getParams)
+      .def("getGame", &GameContext::getGame, ref)
+      .def("getClient", &GameContext::getClient, ref)
+      .def("getServer", &GameContext::getServer)
+      // no reference counterpart: finished-game records as arrays (the reference ships them as JSON
+      // over ZMQ, DistriClient.h:104-122) and the search counters of elfhip_mcts_stats
+      .def("takeRecords", &GameContext::takeRecords)
+      .def("searchStats", &GameContext::searchStats);
+
+  py::class_<DistriClient>(m, "DistriClient")
+      .def("setRequest", &DistriClient::setRequest, py::arg("black_ver"), py::arg("white_ver"), py::arg("numThreads") = -1)
+      .def("getGameStats", &DistriClient::getGameStats, ref);
+
+  py::class_<ContextOptions>(m, "ContextOptions")
+      .def(py::init<>())
+      .def("print", &ContextOptions::print)
+      .def_readwrite("job_id", &ContextOptions::job_id)
+      .def_readwrite("batchsize", &ContextOptions::batchsize)
+      .def_readwrite("num_games", &ContextOptions::num_games)
+      .def_readwrite("T", &ContextOptions::T)
+      .def_readwrite("mcts_options", &ContextOptions::mcts_options);
+
+#define GO_FIELD(f) .def_readwrite(#f, &GameOptions::f)
+  py::class_<GameOptions>(m, "GameOptions")
+      .def(py::init<>())
+      .def("info", &GameOptions::info)
+      GO_FIELD(seed) GO_FIELD(checkers_num_future_actions) GO_FIELD(human_plays_for) GO_FIELD(num_games_per_thread)
+      GO_FIELD(mode) GO_FIELD(use_mcts) GO_FIELD(use_mcts_ai2) GO_FIELD(black_use_policy_network_only)
+      GO_FIELD(white_use_policy_network_only) GO_FIELD(policy_distri_cutoff) GO_FIELD(policy_distri_training_for_all)
+      GO_FIELD(num_reset_ranking) GO_FIELD(q_min_size) GO_FIELD(q_max_size) GO_FIELD(num_reader) GO_FIELD(white_puct)
+      GO_FIELD(white_mcts_rollout_per_batch) GO_FIELD(white_mcts_rollout_per_thread) GO_FIELD(eval_num_games)
+      GO_FIELD(eval_thres) GO_FIELD(client_max_delay_sec) GO_FIELD(selfplay_init_num) GO_FIELD(selfplay_update_num)
+      GO_FIELD(selfplay_async) GO_FIELD(cheat_eval_new_model_wins_half) GO_FIELD(cheat_selfplay_random_result)
+      GO_FIELD(keep_prev_selfplay) GO_FIELD(eval_num_threads) GO_FIELD(expected_num_clients) GO_FIELD(list_files)
+      GO_FIELD(server_addr) GO_FIELD(server_id) GO_FIELD(port) GO_FIELD(verbose) GO_FIELD(dump_record_prefix)
+      GO_FIELD(selfplay_records_directory) GO_FIELD(eval_records_directory) GO_FIELD(records_buffer_directory)
+      GO_FIELD(time_signature);
+#undef GO_FIELD
+
+  py::class_<WinRateStats>(m, "WinRateStats")
+      .def(py::init<>())
+      .def_readwrite("black_wins", &WinRateStats::black_wins)
+      .def_readwrite("white_wins", &WinRateStats::white_wins)
+      .def_readwrite("both_lost", &WinRateStats::both_lost)
+      .def_readwrite("sum_reward", &WinRateStats::sum_reward)
+      .def_readwrite("total_games", &WinRateStats::total_games);
+
+  py::class_<GameStats>(m, "GameStats").def("getWinRateStats", &GameStats::getWinRateStats);
+
+  py::class_<ClientGameSelfPlay>(m, "ClientGameSelfPlay")
+      .def("getCurrentPlayer", &ClientGameSelfPlay::getCurrentPlayer)
+      .def("getValidMoves", &ClientGameSelfPlay::getValidMoves)
+      // the exported state words of include/elfhip.h instead of the reference's 8x8 int board
+      .def("getStateWords", &ClientGameSelfPlay::getStateWords);
+}

@@ -227,6 +227,19 @@ int elfhip_net_load(elfhip_net* n, const float* h_params, long long n_params);
 int elfhip_net_forward(elfhip_net* n, const float* d_s, int batch, float* d_pi, float* d_logpi, float* d_v);
 
 /* ------------------------------------------------------------------------------------------------
+ * Batch-collector copies.  The reference fills a batch by running one copy functor per game state
+ * (SharedMem::waitBatchFillMem / waitReplyReleaseBatch, elf/base/sharedmem.h:144-184, with the
+ * functors of common/GameFeature.h:28-62); here the states of a batch are rows of a device array:
+ *   gather : d_dst[i]          = d_src[d_index[i]]   for i < n_rows   (leaf rows -> dense batch)
+ *   scatter: d_dst[d_index[i]] = d_src[i]                             (dense replies -> leaf slots)
+ * Rows are row_bytes (multiple of 4) bytes.  Enqueued on hip_stream of `device`, no sync.
+ * ---------------------------------------------------------------------------------------------- */
+int elfhip_gather_rows(const void* d_src, long long row_bytes, const int32_t* d_index, int n_rows, void* d_dst, int device,
+                       void* hip_stream);
+int elfhip_scatter_rows(const void* d_src, long long row_bytes, const int32_t* d_index, int n_rows, void* d_dst, int device,
+                        void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Host-only hooks for the explicit libstdc++-order emulations the search kernels use
  * (elf_amd/csrc/stdorder.h).  No reference counterpart: they exist so CPU tests can compare the
  * emulations with the real std::sort / std::unordered_map.

@@ -1,0 +1,61 @@
+"""Minimal stand-in for the reference's GCWrapper / Allocator (src_py/elf/utils_elf.py:16-103,328-514),
+written for the tests: it drives the `_elf` / `_elfgames_*` facade modules through exactly the calls
+the reference's Python makes (createSharedMemOptions, setTimeout, allocateSharedMem, smem[key].field(),
+AnyP.set(ptr, byte_strides), start, wait, effective_batchsize, step, stop)."""
+import os
+import sys
+
+import numpy as np
+
+PYB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "elf_amd", "pybind")
+if PYB not in sys.path:
+    sys.path.insert(0, PYB)
+
+NP_TYPES = {"int32_t": "i4", "int64_t": "i8", "float": "f4", "unsigned char": "u1", "char": "u1"}
+
+
+class Wrapper:
+    def __init__(self, GC, batchsize, desc, num_recv=2):
+        self.GC, self.ctx = GC, GC.ctx()
+        self.batches, self.name2idx, self.idx2name, self.cb = {}, {}, {}, {}
+        for name, v in desc.items():
+            keys_in, keys_rep = list(v.get("input") or []), list(v.get("reply") or [])
+            opts = self.ctx.createSharedMemOptions(name, v.get("batchsize", batchsize))
+            opts.setTimeout(v.get("timeout_usec", 0))
+            for _ in range(num_recv):
+                smem = self.ctx.allocateSharedMem(opts, sorted(set(keys_in + keys_rep)))
+                arrs = {}
+                for k in set(keys_in + keys_rep):
+                    p = smem[k]
+                    f = p.field()
+                    a = np.ones(f.sz().vec(), dtype=NP_TYPES[f.type_name()])
+                    p.set(a.ctypes.data, list(a.strides))
+                    arrs[k] = a
+                idx = smem.getSharedMemOptions().idx()
+                self.batches[idx] = dict(input={k: arrs[k] for k in keys_in}, reply={k: arrs[k] for k in keys_rep})
+                self.name2idx.setdefault(name, []).append(idx)
+                self.idx2name[idx] = name
+
+    def reg_callback(self, name, cb):
+        for idx in self.name2idx[name]:
+            self.cb[idx] = cb
+
+    def start(self):
+        self.ctx.start()
+
+    def run(self):
+        smem = self.ctx.wait()
+        idx = smem.getSharedMemOptions().idx()
+        bs = smem.effective_batchsize()
+        assert bs > 0
+        picked = {k: a[:bs] for k, a in self.batches[idx]["input"].items()}
+        reply = self.cb[idx](picked, bs) if idx in self.cb else None
+        if isinstance(reply, dict):
+            assert set(reply) == set(self.batches[idx]["reply"])
+            for k, v in reply.items():
+                self.batches[idx]["reply"][k][:bs] = v
+        self.ctx.step()
+        return self.idx2name[idx], bs
+
+    def stop(self):
+        self.ctx.stop()

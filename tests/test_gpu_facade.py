@@ -1,0 +1,112 @@
+"""Self-play through the pybind facade (`_elfgames_american_checkers.GameContext` + `_elf.Context`
+wait/step), driven the way the reference's selfplay.py drives it (GCWrapper.run = wait -> callback ->
+step, src_py/elf/utils_elf.py:478-489) with a Python actor callback that returns the uniform policy.
+The finished-game records must equal the oracle's game (moves, uint8 policies, values, reward)
+bit for bit, whatever the batch size the collector cuts the leaves into."""
+import numpy as np
+import pytest
+
+from tests import _gcwrapper
+from tests.test_gpu_selfplay import _oracle_game
+
+pytestmark = pytest.mark.gpu
+
+
+def _context(n_games, batchsize, rollouts, rpb, cutoff=0, two_models=False):
+    import _elfgames_american_checkers as ac
+    co = ac.ContextOptions()
+    co.num_games, co.batchsize = n_games, batchsize
+    m = co.mcts_options
+    m.num_threads, m.num_rollouts_per_thread, m.num_rollouts_per_batch = 1, rollouts, rpb
+    m.virtual_loss, m.alg_opt.c_puct, m.persistent_tree = 1, 1.5, True
+    go = ac.GameOptions()
+    go.mode, go.policy_distri_cutoff, go.policy_distri_training_for_all = "selfplay", cutoff, True
+    GC = ac.GameContext(co, go)
+    desc = dict(game_end=dict(batchsize=1),
+                actor_white=dict(input=["s"], reply=["pi", "V", "a", "rv"], batchsize=batchsize),
+                actor_black=dict(input=["s"], reply=["pi", "V", "a", "rv"], batchsize=batchsize))
+    w = _gcwrapper.Wrapper(GC, batchsize, desc, num_recv=2)
+    if two_models:
+        GC.getClient().setRequest(0, 1, 1)
+    return GC, w
+
+
+def _uniform(batch, bs):
+    s = batch["s"]
+    assert s.shape == (bs, 36, 8, 8)
+    assert np.isin(s, (0.0, 1.0)).all()
+    assert (s[:, 34].reshape(bs, -1).max(1) + s[:, 35].reshape(bs, -1).max(1) == 1).all()   # side-to-move planes of the newest slot
+    return dict(pi=np.full((bs, 170), np.float32(1.0 / 170.0), dtype=np.float32), V=np.zeros(bs, dtype=np.float32),
+                a=np.zeros(bs, dtype=np.int64), rv=np.zeros(bs, dtype=np.int64))
+
+
+@pytest.mark.parametrize("batchsize", [5, 64])
+def test_facade_selfplay_matches_oracle(batchsize):
+    n = 6
+    GC, w = _context(n, batchsize, rollouts=24, rpb=4)
+    counts = dict(actor_black=0, actor_white=0, game_end=0)
+    ends = []
+    w.reg_callback("actor_black", _uniform)
+    w.reg_callback("actor_white", _uniform)
+    w.reg_callback("game_end", lambda batch, bs: ends.append(GC.getClient().getGameStats().getWinRateStats().total_games))
+    w.start()
+    for _ in range(200000):
+        name, bs = w.run()
+        counts[name] += 1
+        assert bs <= (1 if name == "game_end" else batchsize)
+        if len(ends) >= 2 * n:
+            break
+    assert counts["actor_white"] == 0            # one model: every leaf goes to actor_black (_ai1)
+    assert ends == sorted(ends) and ends[-1] >= 2 * n
+    recs = GC.takeRecords()
+    st = GC.searchStats()
+    assert st["rollouts"] > 0 and st["evals"] > 0
+    wr = GC.getClient().getGameStats().getWinRateStats()
+    assert wr.total_games == len(recs) and wr.black_wins + wr.white_wins + wr.both_lost == wr.total_games
+    want = _oracle_game(dict(num_rollouts=24, rollouts_per_batch=4, virtual_loss=1, c_puct=1.5), 0, 2)
+    seen = 0
+    for r in recs:
+        if r["seq"] >= len(want):
+            continue
+        x = want[r["seq"]]
+        assert np.array_equal(np.array(r["moves"], dtype=np.int16), x["moves"])
+        assert np.array_equal(np.array(r["values"], dtype=np.float32), x["values"])
+        assert np.array_equal(np.stack([np.frombuffer(p, dtype=np.uint8) for p in r["policies"]]), x["policies"])
+        assert r["reward"] == x["reward"]
+        seen += 1
+    assert seen >= n
+    g = GC.getGame(0)
+    vm = g.getValidMoves()
+    assert len(vm) == 170 and sum(vm) > 0 and g.getCurrentPlayer() in (0, 1)
+    w.stop()
+    assert GC.ctx().wait() is None
+
+
+def test_facade_two_models_split_by_colour():
+    """setRequest(black_ver, white_ver >= 0): leaves of white-to-move roots go to "actor_white"
+    (curr_ai = white && _ai2 ? _ai2 : _ai1, ClientGameSelfPlay.cc:344-346)."""
+    GC, w = _context(4, 16, rollouts=8, rpb=4, two_models=True)
+    seen = dict(actor_black=0, actor_white=0, game_end=0)
+
+    w.reg_callback("actor_black", _uniform)
+    w.reg_callback("actor_white", _uniform)
+    w.start()
+    for _ in range(400):
+        name, bs = w.run()
+        seen[name] += 1
+    assert seen["actor_black"] > 0 and seen["actor_white"] > 0
+    w.stop()
+
+
+def test_facade_failed_step_keeps_running():
+    import _elf
+    GC, w = _context(2, 8, rollouts=8, rpb=4)
+    w.start()
+    ctx = GC.ctx()
+    for i in range(50):
+        smem = ctx.wait()
+        assert smem.effective_batchsize() > 0
+        ctx.step(_elf.FAILED if i % 2 else _elf.SUCCESS)   # FAILED: the leaf keeps an empty policy (MCTSGameActor.h:122-124)
+    with pytest.raises(RuntimeError):
+        ctx.step()                                          # nothing is out
+    w.stop()
