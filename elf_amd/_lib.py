@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libelfhip.so")
 
 AMERICAN, RUSSIAN, UGOLKI, GO19 = 0, 1, 2, 3
+ELFHIP_F32, ELFHIP_BF16, ELFHIP_BITS = 0, 1, 2
 F32, BF16, BITS = 0, 1, 2
 
 # every symbol include/elfhip.h declares (tests check the .so exports all of them)
@@ -21,9 +22,9 @@ SYMBOLS = [
     "elfhip_boards_playout", "elfhip_test_sort_order", "elfhip_test_umap_order", "elfhip_gather_rows", "elfhip_scatter_rows",
     "elfhip_mcts_create", "elfhip_mcts_destroy", "elfhip_mcts_set_stream", "elfhip_mcts_clear", "elfhip_mcts_set_roots",
     "elfhip_mcts_run_uniform", "elfhip_mcts_select", "elfhip_mcts_backup", "elfhip_mcts_result", "elfhip_mcts_advance",
-    "elfhip_mcts_stats", "elfhip_mcts_pick_moves",
+    "elfhip_mcts_stats", "elfhip_mcts_pick_moves", "elfhip_mcts_seed_rng", "elfhip_mcts_root_noise",
     "elfhip_net_create", "elfhip_net_destroy", "elfhip_net_set_stream", "elfhip_net_param_count", "elfhip_net_load",
-    "elfhip_net_forward",
+    "elfhip_net_forward", "elfhip_net_set_precision",
 ]
 
 
@@ -82,6 +83,10 @@ def lib():
     L.elfhip_test_umap_order.argtypes = [i, vp, vp]
     L.elfhip_mcts_create.argtypes = [i, i, C.POINTER(TSOptions), i, C.POINTER(vp)]
     L.elfhip_mcts_destroy.argtypes = [vp]
+    L.elfhip_mcts_seed_rng.argtypes = [vp, vp]
+    L.elfhip_mcts_root_noise.argtypes = [vp, C.c_float, C.c_float]
+    L.elfhip_gather_rows.argtypes = [vp, C.c_longlong, vp, i, vp, i, vp]
+    L.elfhip_scatter_rows.argtypes = [vp, C.c_longlong, vp, i, vp, i, vp]
     L.elfhip_mcts_set_stream.argtypes = [vp, vp]
     L.elfhip_mcts_clear.argtypes = [vp, vp]
     L.elfhip_mcts_set_roots.argtypes = [vp, vp, vp]
@@ -99,6 +104,7 @@ def lib():
     L.elfhip_net_param_count.restype = C.c_longlong
     L.elfhip_net_load.argtypes = [vp, vp, C.c_longlong]
     L.elfhip_net_forward.argtypes = [vp, vp, i, vp, vp, vp]
+    L.elfhip_net_set_precision.argtypes = [vp, i]
     _lib = L
     return L
 

@@ -301,6 +301,17 @@ int elfhip_mcts_set_roots(elfhip_mcts* h, elfhip_boards* b, uint8_t* d_ok) {
   return h->m->set_roots(b->slab, d_ok);
 }
 
+int elfhip_mcts_seed_rng(elfhip_mcts* h, const uint32_t* h_seeds) { CHECK_M(h); return h->m->seed_rng(h_seeds); }
+
+int elfhip_mcts_root_noise(elfhip_mcts* h, float root_epsilon, float root_alpha) {
+  CHECK_M(h);
+  if (root_epsilon < 0.0f || root_epsilon > 1.0f || (root_epsilon > 0.0f && !(root_alpha > 0.0f))) {
+    elfhip_set_error("mcts_root_noise: need 0 <= root_epsilon <= 1 and root_alpha > 0 (got %g, %g)", root_epsilon, root_alpha);
+    return ELFHIP_EINVAL;
+  }
+  return h->m->root_noise(root_epsilon, root_alpha);
+}
+
 int elfhip_mcts_run_uniform(elfhip_mcts* h) { CHECK_M(h); return h->m->run_uniform(); }
 
 int elfhip_mcts_select(elfhip_mcts* h, uint64_t* d_leaf_states, float* d_leaf_features, uint8_t* d_need_eval) {

@@ -9,6 +9,7 @@
 #pragma once
 #include <cmath>
 #include <new>
+#include <random>
 #include <vector>
 #include "common.h"
 #include "stdorder.h"
@@ -412,6 +413,28 @@ static __global__ void __launch_bounds__(64) mcts_advance_kernel(TreeDev d, cons
   if (lane == 0) { d.t_arena[t] = arena ^ 1; d.t_nnodes[t] = count; d.t_nedges[t] = ecount; }
 }
 
+// NodeT::enhanceExploration (tree_search_node.h:144-167) on the root, device half: the etas are drawn
+// on the host with the real std::gamma_distribution / std::mt19937 (MctsBase::root_noise).
+static __global__ void __launch_bounds__(64) mcts_root_edges_kernel(TreeDev d, int32_t* __restrict__ cnt) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= d.n_trees) return;
+  TV tv = tree_view(d, t, d.t_arena[t]);
+  const uint32_t meta = tv.meta[0];
+  cnt[t] = (d.t_flags[t] == 0 && (meta & 0xFF) == VISITED) ? (int)(meta >> 16) : 0;
+}
+static __global__ void __launch_bounds__(64)
+mcts_root_noise_kernel(TreeDev d, float epsilon, const float* __restrict__ eta, const int32_t* __restrict__ off,
+                       const int32_t* __restrict__ cnt, const float* __restrict__ Z) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int m = cnt[t];
+  if (m == 0) return;
+  TV tv = tree_view(d, t, d.t_arena[t]);
+  const int eb = (int)tv.ebase[0];
+  const float z = Z[t];
+  for (int j = lane; j < m; j += 64)  // prior = (1 - epsilon) * prior + epsilon * etas[i] / Z, float, no contraction
+    tv.ep[eb + j] = (1 - epsilon) * tv.ep[eb + j] + epsilon * eta[off[t] + j] / z;
+}
+
 #define MCTS_ALLOC(ptr, bytes)                                                                  \
   do {                                                                                          \
     if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) {                                     \
@@ -467,6 +490,47 @@ struct MctsBase {
     HIPCHECK(hipMemsetAsync(d.stats, 0, 32, stream));
     HIPCHECK(hipMemsetAsync(d.t_flags, 0, T * 4, stream));
     return clear(nullptr);
+  }
+  // TreeSearchT::run's root noise (tree_search.h:502-506): every tree owns the std::mt19937 of its
+  // actor 0 (MCTSGameActor's rng_, seeded with MCTSActorParams::seed); etas come from the same
+  // libstdc++ std::gamma_distribution<> the reference uses, one draw per root edge in edge order.
+  std::vector<std::mt19937> rngs;
+  int32_t *d_cnt = nullptr, *d_off = nullptr; float *d_Z = nullptr, *d_eta = nullptr;
+  int seed_rng(const uint32_t* h_seeds) {
+    rngs.resize((size_t)d.n_trees);
+    for (int t = 0; t < d.n_trees; ++t) rngs[(size_t)t].seed(h_seeds ? h_seeds[t] : 0u);
+    return ELFHIP_OK;
+  }
+  int root_noise(float epsilon, float alpha) {
+    if (epsilon == 0.0f) return ELFHIP_OK;
+    const size_t T = (size_t)d.n_trees;
+    if (rngs.size() != T) seed_rng(nullptr);
+    if (!d_cnt) {
+      MCTS_ALLOC(d_cnt, T * 4); MCTS_ALLOC(d_off, T * 4); MCTS_ALLOC(d_Z, T * 4); MCTS_ALLOC(d_eta, T * (size_t)num_actions * 4);
+    }
+    hipLaunchKernelGGL(mcts_root_edges_kernel, dim3((d.n_trees + 63) / 64), dim3(64), 0, stream, d, d_cnt);
+    HIPCHECK(hipGetLastError());
+    std::vector<int32_t> cnt(T), off(T);
+    HIPCHECK(hipMemcpyAsync(cnt.data(), d_cnt, T * 4, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    std::vector<float> eta, Z(T, 0.f);
+    for (size_t t = 0; t < T; ++t) {
+      off[t] = (int32_t)eta.size();
+      if (cnt[t] <= 0) continue;
+      if (cnt[t] > num_actions) { elfhip_set_error("mcts_root_noise: tree %zu has %d root edges", t, cnt[t]); return ELFHIP_ESTATE; }
+      std::gamma_distribution<> dis(alpha);
+      float z = 1e-10;
+      for (int i = 0; i < cnt[t]; ++i) { const float e = dis(rngs[t]); eta.push_back(e); z += e; }
+      Z[t] = z;
+    }
+    if (eta.empty()) return ELFHIP_OK;
+    HIPCHECK(hipMemcpyAsync(d_off, off.data(), T * 4, hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipMemcpyAsync(d_Z, Z.data(), T * 4, hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipMemcpyAsync(d_eta, eta.data(), eta.size() * 4, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(mcts_root_noise_kernel, dim3(d.n_trees), dim3(64), 0, stream, d, epsilon, d_eta, d_off, d_cnt, d_Z);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(stream));  // the host vectors go out of scope
+    return ELFHIP_OK;
   }
   int clear(const uint8_t* d_which) {
     hipLaunchKernelGGL(mcts_clear_kernel, dim3(d.n_trees), dim3(64), 0, stream, d, d_which);

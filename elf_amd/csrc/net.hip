@@ -373,10 +373,106 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
   }
 }
 
+
+// ---- fp32 path (north star: policy/value within 1e-5 of the fp32 reference) -----------------------
+// Same implicit GEMM as conv3x3_kernel with fp32 activations / weights and v_mfma_f32_16x16x4_f32
+// (full fp32 products, fp32 accumulate).  BatchNorm is NOT folded into the weights here: the epilogue
+// applies y = acc * scale[co] + shift[co] so the rounding follows conv -> BN of the reference.
+// It exists for parity, not speed: the bf16 board kernel is the product path.
+constexpr int FROW = 36;  // LDS row stride in floats (32 data + 4 pad)
+
+__global__ void net_pack_input_f32_kernel(const float* __restrict__ s, float* __restrict__ x, int B, int C, int H, int W, int CP) {
+  const size_t total = (size_t)B * H * W * CP;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % CP); size_t p = i / CP;
+    int xw = (int)(p % W); p /= W;
+    int y = (int)(p % H); int n = (int)(p / H);
+    x[(((size_t)n * (H + 2) + y + 1) * (W + 2) + xw + 1) * CP + c] = c < C ? s[(((size_t)n * C + c) * H + y) * W + xw] : 0.f;
+  }
+}
+
+template <int COUT>
+__global__ void __launch_bounds__(256)
+conv3x3_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+                   const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int B, int H, int W,
+                   int CIN, int relu) {
+  constexpr int MT = COUT / 16;
+  __shared__ __attribute__((aligned(16))) float sW[COUT * FROW];
+  __shared__ __attribute__((aligned(16))) float sX[BP * FROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = B * H * W;
+  const int m0 = blockIdx.x * BP;
+  const int PW = W + 2;
+  const int srow = tid >> 1, shalf = tid & 1;  // each thread stages 16 channels (64 B) of one position
+  size_t sbase;
+  {
+    int m = min(m0 + srow, M - 1);
+    int xw = m % W, t = m / W, y = t % H, n = t / H;
+    sbase = (((size_t)n * (H + 2) + y + 1) * PW + xw + 1) * CIN;
+  }
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const long toff = ((long)dy * PW + dx) * CIN;
+    for (int c0 = 0; c0 < CIN; c0 += KC) {
+      __syncthreads();
+      {
+        const float4* g = (const float4*)(x + (long)sbase + toff + c0 + shalf * 16);
+        float4* d = (float4*)(sX + srow * FROW + shalf * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = g[q];
+      }
+      for (int i = tid; i < COUT * 8; i += 256) {  // weights: COUT rows x 32 ch = COUT*8 float4
+        const int co = i >> 3, q = i & 7;
+        *(float4*)(sW + co * FROW + q * 4) = *(const float4*)(w + ((size_t)tap * COUT + co) * CIN + c0 + q * 4);
+      }
+      __syncthreads();
+      const int kq = lane >> 4, r16 = lane & 15;
+#pragma unroll
+      for (int kk = 0; kk < KC / 4; ++kk) {
+        const float b0 = sX[(wave * 32 + r16) * FROW + kk * 4 + kq];
+        const float b1 = sX[(wave * 32 + 16 + r16) * FROW + kk * 4 + kq];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float a = sW[(mt * 16 + r16) * FROW + kk * 4 + kq];
+          acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[mt][0], 0, 0, 0);
+          acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[mt][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int m = m0 + wave * 32 + nt * 16 + (lane & 15);
+    if (m >= M) continue;
+    int xw = m % W, t = m / W, y = t % H, n = t / H;
+    const size_t obase = (((size_t)n * (H + 2) + y + 1) * PW + xw + 1) * COUT;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co = mt * 16 + (lane >> 4) * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] * scale[co + r] + shift[co + r];
+      if (res) {
+        const float4 rr = *(const float4*)(res + obase + co);
+        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+      }
+      if (relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      *(float4*)(out + obase + co) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
 // Heads (model_american_checkers.py:339-347), fp32.  One workgroup per board.
 //   pi  = exp(logsoftmax(pi_linear(relu(bn(conv1x1_pi(s))))))     V = tanh(lin2(relu(lin1(relu(bn(conv1x1_v(s)))))))
+template <class T>
 __global__ void __launch_bounds__(256)
-net_heads_kernel(const uint16_t* __restrict__ x, int H, int W, int C, int A,
+net_heads_kernel(const T* __restrict__ x, int H, int W, int C, int A,
                  const float* __restrict__ wpi, float bpi, const float* __restrict__ wv, float bv,
                  const float* __restrict__ pl_w, const float* __restrict__ pl_b,
                  const float* __restrict__ v1_w, const float* __restrict__ v1_b,
@@ -392,16 +488,20 @@ net_heads_kernel(const uint16_t* __restrict__ x, int H, int W, int C, int A,
   const int n = blockIdx.x, tid = threadIdx.x;
   for (int p = tid; p < HW; p += 256) {
     const int y = p / W, xw = p % W;
-    const uint16_t* row = x + (((size_t)n * (H + 2) + y + 1) * (W + 2) + xw + 1) * C;
+    const T* row = x + (((size_t)n * (H + 2) + y + 1) * (W + 2) + xw + 1) * C;
     float a = 0.f, b = 0.f;
-    for (int c = 0; c < C; c += 8) {
-      const uint4 v = *(const uint4*)(row + c);
-      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (sizeof(T) == 4) {
+      for (int c = 0; c < C; ++c) { const float xv = (float)row[c]; a += xv * wpi[c]; b += xv * wv[c]; }
+    } else {
+      for (int c = 0; c < C; c += 8) {
+        const uint4 v = *(const uint4*)(row + c);
+        const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float lo = bf2f((uint16_t)(u[q] & 0xFFFF)), hi = bf2f((uint16_t)(u[q] >> 16));
-        a += lo * wpi[c + 2 * q] + hi * wpi[c + 2 * q + 1];
-        b += lo * wv[c + 2 * q] + hi * wv[c + 2 * q + 1];
+        for (int q = 0; q < 4; ++q) {
+          const float lo = bf2f((uint16_t)(u[q] & 0xFFFF)), hi = bf2f((uint16_t)(u[q] >> 16));
+          a += lo * wpi[c + 2 * q] + hi * wpi[c + 2 * q + 1];
+          b += lo * wv[c + 2 * q] + hi * wv[c + 2 * q + 1];
+        }
       }
     }
     fpi[p] = fmaxf(a + bpi, 0.f);
@@ -468,6 +568,11 @@ struct NetImpl {
   float *wpi = nullptr, *wv = nullptr, *pl_w = nullptr, *pl_b = nullptr, *v1_w = nullptr, *v1_b = nullptr, *v2_w = nullptr;
   float bpi = 0, bv = 0, v2_b = 0;
   uint16_t *xin = nullptr, *act[3] = {nullptr, nullptr, nullptr};
+  // fp32 path (elfhip_net_set_precision(ELFHIP_F32)): unfolded fp32 weights + BN scale / shift
+  struct ConvF { float* w = nullptr; float* sc = nullptr; float* sh = nullptr; int cin = 0; };
+  bool f32 = false;
+  std::vector<ConvF> fconvs;
+  float *fxin = nullptr, *fact[3] = {nullptr, nullptr, nullptr};
   bool loaded = false;
   bool use_board_kernel = true;   // ELFHIP_NET_TILE=positions selects the generic position-tiled kernel
   ~NetImpl() { for (void* p : allocs) (void)hipFree(p); }
@@ -502,9 +607,49 @@ struct NetImpl {
     return ELFHIP_OK;
   }
 
+  int alloc_f32() {
+    if (!fconvs.empty()) return ELFHIP_OK;
+    const int d = cfg.dim, H = cfg.board;
+    const size_t pos = (size_t)max_batch * (H + 2) * (H + 2);
+    NALLOC(fxin, pos * cin_pad * 4);
+    for (int i = 0; i < 3; ++i) NALLOC(fact[i], pos * d * 4);
+    HIPCHECK(hipMemsetAsync(fxin, 0, pos * cin_pad * 4, stream));
+    for (int i = 0; i < 3; ++i) HIPCHECK(hipMemsetAsync(fact[i], 0, pos * d * 4, stream));
+    fconvs.resize(1 + 2 * cfg.num_block);
+    for (size_t i = 0; i < fconvs.size(); ++i) {
+      fconvs[i].cin = i == 0 ? cin_pad : d;
+      NALLOC(fconvs[i].w, (size_t)9 * d * fconvs[i].cin * 4);
+      NALLOC(fconvs[i].sc, (size_t)d * 4); NALLOC(fconvs[i].sh, (size_t)d * 4);
+    }
+    return ELFHIP_OK;
+  }
+
+  int load_f32(const float* h) {
+    const int d = cfg.dim;
+    const float* p = h;
+    for (size_t li = 0; li < fconvs.size(); ++li) {
+      const int cin = li == 0 ? cfg.planes : d, cp = fconvs[li].cin;
+      const float* wt = p; p += (size_t)d * cin * 9;
+      const float* cb = p; p += d;
+      const float *g = p, *be = p + d, *mu = p + 2 * d, *var = p + 3 * d; p += 4 * d;
+      std::vector<float> wq((size_t)9 * d * cp, 0.f), sc(d), sh(d);
+      for (int co = 0; co < d; ++co) {
+        sc[co] = g[co] / std::sqrt(var[co] + cfg.bn_eps);
+        sh[co] = (cb[co] - mu[co]) * sc[co] + be[co];
+        for (int ci = 0; ci < cin; ++ci)
+          for (int t = 0; t < 9; ++t) wq[((size_t)t * d + co) * cp + ci] = wt[((size_t)co * cin + ci) * 9 + t];
+      }
+      HIPCHECK(hipMemcpy(fconvs[li].w, wq.data(), wq.size() * 4, hipMemcpyHostToDevice));
+      HIPCHECK(hipMemcpy(fconvs[li].sc, sc.data(), (size_t)d * 4, hipMemcpyHostToDevice));
+      HIPCHECK(hipMemcpy(fconvs[li].sh, sh.data(), (size_t)d * 4, hipMemcpyHostToDevice));
+    }
+    return ELFHIP_OK;
+  }
+
   // h = flat fp32 parameters in the reference's state_dict order (see elfhip.h); folds BN, casts to bf16
   int load(const float* h, size_t n) {
     if (n != param_count()) { elfhip_set_error("net_load: expected %zu floats, got %zu", param_count(), n); return ELFHIP_EINVAL; }
+    if (f32) { int rc = load_f32(h); if (rc) return rc; }
     const int d = cfg.dim, H = cfg.board;
     const size_t hw = (size_t)H * H;
     auto bf = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
@@ -591,7 +736,42 @@ struct NetImpl {
     }
   }
 
+  template <int COUT>
+  void launch_conv_f32(const float* x, const ConvF& c, const float* res, float* out, int B, int relu) {
+    const int M = B * cfg.board * cfg.board;
+    hipLaunchKernelGGL(conv3x3_f32_kernel<COUT>, dim3((M + BP - 1) / BP), dim3(256), 0, stream, x, c.w, c.sc, c.sh, res, out, B,
+                       cfg.board, cfg.board, c.cin, relu);
+  }
+  void conv_f32(const float* x, const ConvF& c, const float* res, float* out, int B, int relu) {
+    switch (cfg.dim) {
+      case 32: launch_conv_f32<32>(x, c, res, out, B, relu); break;
+      case 64: launch_conv_f32<64>(x, c, res, out, B, relu); break;
+      case 128: launch_conv_f32<128>(x, c, res, out, B, relu); break;
+      case 224: launch_conv_f32<224>(x, c, res, out, B, relu); break;
+      default: launch_conv_f32<256>(x, c, res, out, B, relu); break;
+    }
+  }
+  int forward_f32(const float* d_s, int B, float* d_pi, float* d_logpi, float* d_v) {
+    const int H = cfg.board;
+    hipLaunchKernelGGL(net_pack_input_f32_kernel, dim3(std::min<size_t>(4096, ((size_t)B * H * H * cin_pad + 255) / 256)),
+                       dim3(256), 0, stream, d_s, fxin, B, cfg.planes, H, H, cin_pad);
+    conv_f32(fxin, fconvs[0], nullptr, fact[0], B, 1);
+    int cur = 0;
+    for (int k = 0; k < cfg.num_block; ++k) {
+      const int t1 = (cur + 1) % 3, t2 = (cur + 2) % 3;
+      conv_f32(fact[cur], fconvs[1 + 2 * k], nullptr, fact[t1], B, 1);
+      conv_f32(fact[t1], fconvs[2 + 2 * k], fact[cur], fact[t2], B, 1);
+      cur = t2;
+    }
+    const size_t sm = ((size_t)2 * H * H + cfg.num_action + 256) * 4;
+    hipLaunchKernelGGL(net_heads_kernel<float>, dim3(B), dim3(256), sm, stream, fact[cur], H, H, cfg.dim, cfg.num_action, wpi, bpi,
+                       wv, bv, pl_w, pl_b, v1_w, v1_b, v2_w, v2_b, d_pi, d_logpi, d_v);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+
   int forward(const float* d_s, int B, float* d_pi, float* d_logpi, float* d_v) {
+    if (f32) return forward_f32(d_s, B, d_pi, d_logpi, d_v);
     const int H = cfg.board;
     hipLaunchKernelGGL(net_pack_input_kernel, dim3(std::min<size_t>(4096, ((size_t)B * H * H * cin_pad + 255) / 256)), dim3(256),
                        0, stream, d_s, xin, B, cfg.planes, H, H, cin_pad);
@@ -604,7 +784,7 @@ struct NetImpl {
       cur = t2;
     }
     const size_t sm = ((size_t)2 * H * H + cfg.num_action + 256) * 4;
-    hipLaunchKernelGGL(net_heads_kernel, dim3(B), dim3(256), sm, stream, act[cur], H, H, cfg.dim, cfg.num_action, wpi, bpi, wv,
+    hipLaunchKernelGGL(net_heads_kernel<uint16_t>, dim3(B), dim3(256), sm, stream, act[cur], H, H, cfg.dim, cfg.num_action, wpi, bpi, wv,
                        bv, pl_w, pl_b, v1_w, v1_b, v2_w, v2_b, d_pi, d_logpi, d_v);
     HIPCHECK(hipGetLastError());
     return ELFHIP_OK;
@@ -657,6 +837,14 @@ long long elfhip_net_param_count(const elfhip_net_config* cfg) {
   if (!cfg) return ELFHIP_EINVAL;
   NetImpl t; t.cfg = *cfg;
   return (long long)t.param_count();
+}
+
+int elfhip_net_set_precision(elfhip_net* h, int dtype) {
+  CHECK_N(h);
+  if (dtype != ELFHIP_F32 && dtype != ELFHIP_BF16) { elfhip_set_error("net_set_precision: dtype must be ELFHIP_F32 or ELFHIP_BF16"); return ELFHIP_EINVAL; }
+  if (h->n->loaded) { elfhip_set_error("net_set_precision: call before elfhip_net_load"); return ELFHIP_ESTATE; }
+  h->n->f32 = dtype == ELFHIP_F32;
+  return h->n->f32 ? h->n->alloc_f32() : ELFHIP_OK;
 }
 
 int elfhip_net_load(elfhip_net* h, const float* h_params, long long n_params) {

@@ -14,7 +14,8 @@ from ._lib import TSOptions, check
 class TreeSearchBatch:
     def __init__(self, game, n_trees, device=0, num_rollouts_per_thread=100, num_rollouts_per_batch=8, virtual_loss=0,
                  use_prior=True, c_puct=5.0, unexplored_q_zero=False, root_unexplored_q_zero=False,
-                 persistent_tree=True, pick_method="most_visited", max_nodes=0, max_edges=0):
+                 persistent_tree=True, pick_method="most_visited", max_nodes=0, max_edges=0,
+                 root_epsilon=0.0, root_alpha=0.0, seeds=None):
         self.L = _lib.lib()
         self.n = int(n_trees)
         self.B = int(num_rollouts_per_batch)
@@ -27,6 +28,9 @@ class TreeSearchBatch:
         h = C.c_void_p()
         check(self.L.elfhip_mcts_create(game, self.n, C.byref(self.opt), device, C.byref(h)))
         self.h = h
+        self.root_epsilon, self.root_alpha = float(root_epsilon), float(root_alpha)
+        if seeds is not None:
+            self.seed_rng(seeds)
 
     def close(self):
         if getattr(self, "h", None):
@@ -45,9 +49,22 @@ class TreeSearchBatch:
     def clear(self, which=None):
         check(self.L.elfhip_mcts_clear(self.h, which.data_ptr() if which is not None else None))
 
-    def set_roots(self, boards):
+    def _set_roots(self, boards):
         ok = torch.empty(self.n, dtype=torch.uint8, device=self.device)
         check(self.L.elfhip_mcts_set_roots(self.h, boards.h, ok.data_ptr()))
+        return ok
+
+    def seed_rng(self, seeds):
+        """per-tree std::mt19937 seeds of the root-noise generator (MCTSActorParams.seed)"""
+        a = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint32))
+        assert a.shape == (self.n,)
+        check(self.L.elfhip_mcts_seed_rng(self.h, a.ctypes.data))
+
+    def set_roots(self, boards):
+        """TreeSearchT::run's prologue: setRootNodeState, then enhanceExploration when root_epsilon > 0"""
+        ok = self._set_roots(boards)
+        if self.root_epsilon > 0.0:
+            check(self.L.elfhip_mcts_root_noise(self.h, self.root_epsilon, self.root_alpha))
         return ok
 
     def run_uniform(self):

@@ -40,7 +40,7 @@ def pack_state_dict(sd, num_block):
 
 
 class PolicyValueNet:
-    def __init__(self, planes=36, board=8, dim=128, num_block=10, num_action=170, bn_eps=1e-5, max_batch=4096, device=0):
+    def __init__(self, planes=36, board=8, dim=128, num_block=10, num_action=170, bn_eps=1e-5, max_batch=4096, device=0, precision="bf16"):
         self.L = _lib.lib()
         self.cfg = NetConfig(planes, board, dim, num_block, num_action, bn_eps)
         self.max_batch = max_batch
@@ -48,6 +48,8 @@ class PolicyValueNet:
         h = C.c_void_p()
         check(self.L.elfhip_net_create(C.byref(self.cfg), max_batch, device, C.byref(h)))
         self.h = h
+        # "bf16": MFMA product path (1e-2 abs); "f32": the reference's non-fp16 mode (1e-5 abs)
+        check(self.L.elfhip_net_set_precision(self.h, {"bf16": _lib.ELFHIP_BF16, "f32": _lib.ELFHIP_F32}[precision]))
 
     def close(self):
         if getattr(self, "h", None):

@@ -21,6 +21,7 @@
 #include <array>
 #include <cstdlib>
 #include <cstring>
+#include <random>
 
 #include "../../include/elfhip.h"
 #include "facade.h"
@@ -173,7 +174,6 @@ class SelfPlayEngine : public elfhip_py::Engine {
     if (by_label_.find("actor_black") == by_label_.end())
       throw std::runtime_error("GameContext: no 'actor_black' batch was allocated (game.py:383-397)");
     const TSOptions& t = co_.mcts_options;
-    if (t.root_epsilon != 0.0f) throw std::range_error("GameContext: root_epsilon != 0 is not built");
     if (t.pick_method != "most_visited" && t.pick_method != "strongest_prior")
       throw std::range_error("MCTS Pick method unknown! " + t.pick_method);  // tree_search.h:615
     hk(hipSetDevice(device_), "hipSetDevice");
@@ -187,6 +187,11 @@ class SelfPlayEngine : public elfhip_py::Engine {
                         t.persistent_tree ? 1 : 0, t.pick_method == "most_visited" ? 0 : 1, 0, 0};
     ck(elfhip_boards_create(game_, n_, device_, &boards_), "boards_create");
     ck(elfhip_mcts_create(game_, n_, &o, device_, &mcts_), "mcts_create");
+    {  // the reference seeds each game's rng with GameOptions.seed (GameBase.h:43-49) and the actor's with its first draw
+      std::vector<uint32_t> seeds(n_);
+      for (int i = 0; i < n_; ++i) { std::mt19937 g(go_.seed + (unsigned)i); seeds[i] = (uint32_t)g(); }
+      ck(elfhip_mcts_seed_rng(mcts_, seeds.data()), "mcts_seed_rng");
+    }
     const size_t slots = (size_t)n_ * B_, A = gi_.num_actions;
     feat_row_ = (size_t)gi_.num_planes * gi_.board_size * gi_.board_size * 4;
     max_chunk_ = 1;
@@ -215,6 +220,8 @@ class SelfPlayEngine : public elfhip_py::Engine {
       switch (phase_) {
         case BEGIN:
           ck(elfhip_mcts_set_roots(mcts_, boards_, nullptr), "mcts_set_roots");
+          if (co_.mcts_options.root_epsilon > 0.0f)  // TreeSearchT::run, tree_search.h:502-506
+            ck(elfhip_mcts_root_noise(mcts_, co_.mcts_options.root_epsilon, co_.mcts_options.root_alpha), "mcts_root_noise");
           rollouts_ = 0;
           phase_ = SELECT;
           break;

@@ -122,8 +122,7 @@ int elfhip_boards_playout(elfhip_boards* b, int nply, uint64_t seed, uint64_t fi
  * mcts.h:48-203) run with num_threads == 1, and the game actor MCTSGameActor (pre_evaluate /
  * pi2response, MCTSGameActor.h:198-335).  Field names follow TSOptions / SearchAlgoOptions
  * (tree_search_options.h:24-29,91-110); num_threads is fixed to 1 because bit-exact results are
- * only defined there (hard part 3).  root_epsilon / root_alpha (Dirichlet-like root
- * noise) are not built yet and must be 0.
+ * only defined there (hard part 3).  root_epsilon / root_alpha: see elfhip_mcts_root_noise.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   int num_rollouts_per_thread; /* rollouts per run() */
@@ -150,6 +149,17 @@ int elfhip_mcts_clear(elfhip_mcts* m, const uint8_t* d_which);
  * tree first when persistent_tree == 0, mcts.h:167-173).  d_ok (nullable) [n_trees] u8: 0 where the
  * stored root state differs from the board ("Root state is not the same"); such trees are parked. */
 int elfhip_mcts_set_roots(elfhip_mcts* m, elfhip_boards* b, uint8_t* d_ok);
+/* Root exploration noise of TreeSearchT::run (tree_search.h:502-506 -> NodeT::enhanceExploration,
+ * tree_search_node.h:144-167): call after set_roots and before the rollouts of a move.  For every
+ * tree whose root has edges: eta_i ~ std::gamma_distribution<>(root_alpha) drawn from the tree's own
+ * std::mt19937 (one draw per edge, in edge order), Z = 1e-10f + sum eta_i (float),
+ * prior_i = (1 - root_epsilon) * prior_i + root_epsilon * eta_i / Z.  As in the reference a root that
+ * has not been evaluated yet (fresh tree, or non-persistent trees always) has no edges and gets no
+ * noise.  The draws use the host's libstdc++ (same as the reference); synchronises the stream.
+ * elfhip_mcts_seed_rng: h_seeds u32 [n_trees] (nullable = all 0) re-seeds the per-tree generators
+ * (MCTSActorParams::seed, MCTSGameActor.h; the reference draws them from the game's own rng). */
+int elfhip_mcts_seed_rng(elfhip_mcts* m, const uint32_t* h_seeds);
+int elfhip_mcts_root_noise(elfhip_mcts* m, float root_epsilon, float root_alpha);
 /* TreeSearchT::run with the uniform evaluator (pi = 1/num_actions before filtering, V = 0, terminal
  * +-1): all ceil(rollouts/batch) batches inside ONE launch.  BASELINE.json configs[2]. */
 int elfhip_mcts_run_uniform(elfhip_mcts* m);
@@ -221,6 +231,11 @@ int elfhip_net_create(const elfhip_net_config* cfg, int max_batch, int device, e
 int elfhip_net_destroy(elfhip_net* n);
 int elfhip_net_set_stream(elfhip_net* n, void* hip_stream);
 long long elfhip_net_param_count(const elfhip_net_config* cfg);
+/* Arithmetic of the residual tower: ELFHIP_BF16 (default: bf16 activations / weights on the MFMA path,
+ * fp32 accumulate, within 1e-2 abs of the fp32 reference) or ELFHIP_F32 (fp32 activations / weights,
+ * v_mfma_f32_16x16x4_f32, BatchNorm applied unfolded after the convolution; within 1e-5 abs - the
+ * reference's own non-FP16Model mode, utils/fp16_utils.py:31-43 off).  Call before elfhip_net_load. */
+int elfhip_net_set_precision(elfhip_net* n, int dtype);
 int elfhip_net_load(elfhip_net* n, const float* h_params, long long n_params);
 /* d_s: float [batch][planes][board][board] (the "s" key); outputs float: d_pi [batch][num_action],
  * d_logpi (nullable) same shape, d_v [batch]. */

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <random>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -132,6 +133,18 @@ struct Mcts {
   std::unordered_map<int, std::unique_ptr<Node>> nodes;  // TreeT::allocatedNodes_
   int next_id = 0, root = -1;
   long evals = 0, rollouts = 0, depth_sum = 0, edge_sum = 0;
+  float root_epsilon = 0.f, root_alpha = 0.f;
+  std::mt19937 rng;  // actors_[0]->rng()
+
+  void enhance_exploration(Node* n) {  // tree_search_node.h:144-167
+    if (root_epsilon == 0.0) return;
+    std::gamma_distribution<> dis(root_alpha);
+    std::vector<float> etas(n->edges.size());
+    float Z = 1e-10;
+    for (size_t i = 0; i < n->edges.size(); ++i) { etas[i] = dis(rng); Z += etas[i]; }
+    int i = 0;
+    for (auto& p : n->edges) { p.second.prior = (1 - root_epsilon) * p.second.prior + root_epsilon * etas[i] / Z; i++; }
+  }
 
   Mcts() { clear(); }
   int add_node(float pq) { nodes[next_id].reset(new Node(pq)); return next_id++; }
@@ -275,6 +288,7 @@ int run(Mcts<G>* m, const typename G::State* g, int max_edges, int* n_edges, uin
   auto* rootn = m->get(m->root);
   if (!rootn->state) rootn->state.reset(new State(*g));   // setRootNodeState
   if (!G::same(*rootn->state, *g)) return -2;              // "Root state is not the same"
+  if (m->root_epsilon > 0.0) m->enhance_exploration(rootn); // TreeSearchT::run tree_search.h:502-506
   for (int idx = 0; idx < m->opt.num_rollouts; idx += m->opt.num_rollouts_per_batch) m->batch_rollouts(rootn);
   // MCTSResultT::addActions tree_search_base.h:310-367
   float max_score = std::numeric_limits<float>::lowest();
@@ -301,6 +315,7 @@ using GoMcts = Mcts<GoTraits>;
 
 void* omcts_create(const int* iopt, float c_puct, int policy_kind, uint64_t policy_seed) { return create<AmTraits>(iopt, c_puct, policy_kind, policy_seed); }
 void omcts_set_callback(void* h, void (*cb)(const uint64_t*, float*, float*)) { ((AmMcts*)h)->policy_cb = cb; }
+void omcts_set_noise(void* h, float eps, float alpha, unsigned seed) { AmMcts* m = (AmMcts*)h; m->root_epsilon = eps; m->root_alpha = alpha; m->rng.seed(seed); }
 void omcts_destroy(void* h) { delete (AmMcts*)h; }
 void omcts_clear(void* h) { ((AmMcts*)h)->clear(); }                       // MCTSAI_T::resetTree / endGame
 void omcts_advance(void* h, int action) { ((AmMcts*)h)->tree_advance((Action)action); }  // advanceMoves
@@ -308,6 +323,7 @@ void omcts_stats(void* h, long* out4) { AmMcts* m = (AmMcts*)h; out4[0] = m->rol
 
 void* ogomcts_create(const int* iopt, float c_puct, int policy_kind, uint64_t policy_seed) { return create<GoTraits>(iopt, c_puct, policy_kind, policy_seed); }
 void ogomcts_set_callback(void* h, void (*cb)(const uint64_t*, float*, float*)) { ((GoMcts*)h)->policy_cb = cb; }
+void ogomcts_set_noise(void* h, float eps, float alpha, unsigned seed) { GoMcts* m = (GoMcts*)h; m->root_epsilon = eps; m->root_alpha = alpha; m->rng.seed(seed); }
 void ogomcts_destroy(void* h) { delete (GoMcts*)h; }
 void ogomcts_clear(void* h) { ((GoMcts*)h)->clear(); }
 void ogomcts_advance(void* h, int action) { ((GoMcts*)h)->tree_advance((Action)action); }

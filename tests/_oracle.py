@@ -388,6 +388,11 @@ class OracleMcts:
         return dict(best=best, edges=[(int(acts[i]), int(vis[i]), float(rew[i]), float(pri[i])) for i in range(k)],
                     total_visits=int(tv[0]), root_value=float(rv[0]), best_q=float(bq[0]))
 
+    def set_noise(self, eps, alpha, seed):
+        f = getattr(self.L, self.pre + "set_noise")
+        f.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint]
+        f(self.h, eps, alpha, seed)
+
     def advance(self, a):
         getattr(self.L, self.pre + "advance")(self.h, int(a))
 
