@@ -43,7 +43,7 @@ def build(force=False, verbose=False):
 # Python-visible facade modules with the reference's module names (host C++ only, g++):
 # _elf and one _elfgames_<game> per game that has search kernels.
 PYB = os.path.join(HERE, "pybind")
-GAME_MODULES = {"_elfgames_american_checkers": 0}
+GAME_MODULES = {"_elfgames_american_checkers": 0, "_elfgames_russian_checkers": 1, "_elfgames_ugolki": 2}
 
 
 def build_pybind(force=False, verbose=False):

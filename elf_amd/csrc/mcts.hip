@@ -256,10 +256,7 @@ extern "C" {
 int elfhip_mcts_create(int game, int n_trees, const elfhip_ts_options* opt, int device, elfhip_mcts** out) {
   if (!out || !opt) { elfhip_set_error("mcts_create: null argument"); return ELFHIP_EINVAL; }
   *out = nullptr;
-  if (game != ELFHIP_AMERICAN && game != ELFHIP_GO19) {
-    elfhip_set_error("mcts_create: game %d has no search kernels (american checkers and go19 only)", game);
-    return ELFHIP_EINVAL;
-  }
+  if (game < ELFHIP_AMERICAN || game > ELFHIP_GO19) { elfhip_set_error("mcts_create: unknown game %d", game); return ELFHIP_EINVAL; }
   if (n_trees <= 0 || n_trees > (1 << 22)) { elfhip_set_error("mcts_create: n_trees=%d out of range", n_trees); return ELFHIP_EINVAL; }
   if (opt->num_rollouts_per_batch < 1 || opt->num_rollouts_per_batch > mcts::MAXB) {
     elfhip_set_error("mcts_create: num_rollouts_per_batch=%d not in [1,%d]", opt->num_rollouts_per_batch, mcts::MAXB);
@@ -274,7 +271,10 @@ int elfhip_mcts_create(int game, int n_trees, const elfhip_ts_options* opt, int 
   if (device < 0 || device >= ndev) { elfhip_set_error("mcts_create: device %d not in [0,%d)", device, ndev); return ELFHIP_EINVAL; }
   HIPCHECK(hipSetDevice(device));
   int rc = ELFHIP_OK;
-  mcts::MctsBase* m = game == ELFHIP_AMERICAN ? elfhip_make_mcts_american(n_trees, opt, &rc) : elfhip_make_mcts_go(n_trees, opt, &rc);
+  mcts::MctsBase* m = game == ELFHIP_AMERICAN  ? elfhip_make_mcts_american(n_trees, opt, &rc)
+                      : game == ELFHIP_RUSSIAN ? elfhip_make_mcts_russian(n_trees, opt, &rc)
+                      : game == ELFHIP_UGOLKI  ? elfhip_make_mcts_ugolki(n_trees, opt, &rc)
+                                               : elfhip_make_mcts_go(n_trees, opt, &rc);
   if (!m) return rc;
   m->device = device; m->game = game;
   *out = new elfhip_mcts{m};

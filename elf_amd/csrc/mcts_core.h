@@ -543,3 +543,5 @@ struct MctsBase {
 
 mcts::MctsBase* elfhip_make_mcts_american(int n_trees, const elfhip_ts_options* opt, int* rc);
 mcts::MctsBase* elfhip_make_mcts_go(int n_trees, const elfhip_ts_options* opt, int* rc);
+mcts::MctsBase* elfhip_make_mcts_russian(int n_trees, const elfhip_ts_options* opt, int* rc);
+mcts::MctsBase* elfhip_make_mcts_ugolki(int n_trees, const elfhip_ts_options* opt, int* rc);

@@ -11,239 +11,10 @@
 // base[dir][dist] + popcount(valid from-squares above the origin) - no tables, no strings.
 #include "common.h"
 
+#include "russian_dev.h"
+
 namespace {
-
-constexpr int RU_ACTIONS = 280, RU_MAX_PLY = 250, RU_M_INVALID = 281;
-constexpr uint64_t RU_DARK = 0x55AA55AA55AA55AAull;  // (y + x) odd, bit = y*8 + x
-constexpr uint64_t RU_X0 = 0x0101010101010101ull;
-
-struct Ru { uint64_t wp, wk, bp, bk, w4; };  // w4: see include/elfhip.h (state layout of ELFHIP_RUSSIAN)
-
-__host__ __device__ constexpr bool ru_white(uint64_t w4) { return w4 & 1; }
-__host__ __device__ constexpr int ru_ply(uint64_t w4) { return (int)((w4 >> 8) & 0xFFFF); }
-
-// direction k in the order of the reference's action table (HashAllMoves.h):
-//   0 = (dy-1,dx+1)  1 = (-1,-1)  2 = (+1,-1)  3 = (+1,+1);   inverse direction = k ^ 2
-__host__ __device__ constexpr uint64_t ru_wrap(int k) {  // squares a one-step shift may legally land on
-  return (k == 0 || k == 3) ? ~RU_X0 : ~(RU_X0 << 7);
-}
-__host__ __device__ constexpr uint64_t ru_shn(uint64_t b, int k, int steps) {  // raw shift, no wrap mask
-  return k == 0 ? b >> (7 * steps) : k == 1 ? b >> (9 * steps) : k == 2 ? b << (7 * steps) : b << (9 * steps);
-}
-__host__ __device__ constexpr uint64_t ru_sh(uint64_t b, int k) { return ru_shn(b, k, 1) & ru_wrap(k); }
-
-// from-squares whose destination d steps along k stays on the board (closed form)
-__host__ __device__ constexpr uint64_t ru_valid(int k, int d) {
-  uint64_t rows = (k < 2) ? (~0ull << (8 * d)) : (~0ull >> (8 * d));
-  uint64_t cols = (k == 0 || k == 3) ? RU_X0 * (uint64_t)((1u << (8 - d)) - 1u) : RU_X0 * (uint64_t)((0xFFu << d) & 0xFFu);
-  return RU_DARK & rows & cols;
-}
-__host__ __device__ constexpr int ru_popc(uint64_t v) { int c = 0; for (; v; v &= v - 1) ++c; return c; }
-// first action index of group (k, d): groups are ordered k-major, d = 1..7
-__host__ __device__ constexpr int ru_base(int k, int d) {
-  int b = 0;
-  for (int kk = 0; kk < 4; ++kk)
-    for (int dd = 1; dd < 8; ++dd) {
-      if (kk == k && dd == d) return b;
-      b += ru_popc(ru_valid(kk, dd));
-    }
-  return b;
-}
-static_assert(ru_base(3, 7) + ru_popc(ru_valid(3, 7)) == RU_ACTIONS, "russian action table size");
-
-// action -> from | to << 6, generated by the same rule (descending from-square inside a group)
-struct RuActTab { uint16_t ft[RU_ACTIONS]; };
-constexpr RuActTab ru_make_acttab() {
-  RuActTab t{};
-  int n = 0;
-  for (int k = 0; k < 4; ++k)
-    for (int d = 1; d < 8; ++d) {
-      uint64_t v = ru_valid(k, d);
-      for (int s = 63; s >= 0; --s)
-        if ((v >> s) & 1) {
-          int to = (k < 2) ? s - (k == 0 ? 7 : 9) * d : s + (k == 2 ? 7 : 9) * d;
-          t.ft[n++] = (uint16_t)(s | (to << 6));
-        }
-    }
-  return t;
-}
-static __constant__ RuActTab c_ru_act = ru_make_acttab();
-
-// Kogge-Stone occluded fill: everything reachable from `gen` along k through `pro` (gen included)
-__device__ inline uint64_t ru_fill(uint64_t gen, uint64_t pro, int k) {
-  pro &= ru_wrap(k);
-  gen |= pro & ru_shn(gen, k, 1);
-  pro &= ru_shn(pro, k, 1);
-  gen |= pro & ru_shn(gen, k, 2);
-  pro &= ru_shn(pro, k, 2);
-  gen |= pro & ru_shn(gen, k, 4);
-  return gen;
-}
-
-__device__ inline void ru_set_bit(uint64_t m[5], int idx) {
-  uint64_t bit = 1ull << (idx & 63);
-  int w = idx >> 6;
-#pragma unroll
-  for (int i = 0; i < 5; ++i) m[i] |= (i == w) ? bit : 0ull;
-}
-
-// all from-squares of `from` move d steps along k
-__device__ inline void ru_emit_group(uint64_t m[5], uint64_t from, int k, int d) {
-  const uint64_t valid = ru_valid(k, d);
-  const int base = ru_base(k, d);
-  while (from) {
-    uint64_t o = from & (0 - from);
-    from ^= o;
-    ru_set_bit(m, base + __popcll(valid & ~(o | (o - 1))));
-  }
-}
-// one origin, a set of destinations along k
-__device__ inline void ru_emit_ray(uint64_t m[5], uint64_t o, uint64_t dests, int k) {
-  const uint64_t above = ~(o | (o - 1));
-  uint64_t t = o;
-#pragma unroll
-  for (int d = 1; d < 8; ++d) {
-    t = ru_sh(t, k);
-    if (dests & t) ru_set_bit(m, ru_base(k, d) + __popcll(ru_valid(k, d) & above));
-  }
-}
-
-__device__ inline void ru_clear(Ru& s) {  // ClearBoard CheckersBoard.cc:10-33
-  s.wp = RU_DARK & 0xFFFFFFull; s.wk = 0; s.bp = RU_DARK & (0xFFFFFFull << 40); s.bk = 0;
-  s.w4 = (1ull << 8) | ((uint64_t)RU_M_INVALID << 24);
-}
-
-// getAllMoves CheckersBoard.cc:259-273 -> 280-bit legal mask
-__device__ inline void ru_moves(const Ru& s, uint64_t m[5]) {
-#pragma unroll
-  for (int i = 0; i < 5; ++i) m[i] = 0;
-  const bool white = ru_white(s.w4);
-  uint64_t P = white ? s.wp : s.bp, K = white ? s.wk : s.bk;
-  const uint64_t enemy = white ? (s.bp | s.bk) : (s.wp | s.wk);
-  const uint64_t occ = s.wp | s.wk | s.bp | s.bk, empty = ~occ;
-  const bool has_next = (s.w4 >> 1) & 1;
-  if (has_next) {  // only the piece that just captured may move, and only by capturing (:262-263)
-    uint64_t nb = 1ull << ((((s.w4 >> 2) & 7) << 3) | ((s.w4 >> 5) & 7));  // next_y<<2 | next_x<<5
-    K = nb & (s.wk | s.bk);
-    P = nb & ~(s.wk | s.bk);
-  }
-  bool any = false;
-  // _pawnJumpInDirection :593-628 - all pawns at once
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    uint64_t land = ru_sh(ru_sh(P, k) & enemy, k) & empty;
-    uint64_t from = ru_sh(ru_sh(land, k ^ 2), k ^ 2);
-    any |= from != 0;
-    ru_emit_group(m, from, k, 2);
-  }
-  // _kingJumpInDirection :457-530 - per king, per direction
-  for (uint64_t kk = K; kk;) {
-    uint64_t o = kk & (0 - kk);
-    kk ^= o;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      uint64_t cap = ru_sh(ru_fill(o, empty, k), k) & enemy;     // first piece on the ray, if an enemy
-      uint64_t land = ru_sh(cap, k) & empty;
-      if (land) {
-        const uint64_t emp2 = empty | cap, en2 = enemy & ~cap;   // captured piece lifted (:488)
-        uint64_t L = ru_fill(land, emp2, k);
-        // squares from which a king sees "enemy, then empty" in some direction (_kingJumpCheck :412-453)
-        uint64_t C = 0;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          uint64_t T = en2 & ru_sh(emp2, d ^ 2);
-          C |= ru_fill(ru_sh(T, d ^ 2) & emp2, emp2, d ^ 2);
-        }
-        uint64_t Lc = L & C;
-        if (Lc) L = (k >= 2) ? (Lc & (0 - Lc)) : (1ull << (63 - __clzll((long long)Lc)));  // nearest one only (:505-513)
-        ru_emit_ray(m, o, L, k);
-        any = true;
-      }
-    }
-  }
-  if (any || has_next) return;
-  // simple moves: pawns forward only (:317-346), kings slide (:348-404)
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if ((k >= 2) == white) ru_emit_group(m, P & ru_sh(empty, k ^ 2), k, 1);
-  }
-  for (uint64_t kk = K; kk;) {
-    uint64_t o = kk & (0 - kk);
-    kk ^= o;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      uint64_t L = ru_fill(ru_sh(o, k) & empty, empty, k);
-      if (L) ru_emit_ray(m, o, L, k);
-    }
-  }
-}
-
-__device__ inline int ru_count(const uint64_t m[5]) {
-  return __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]) + __popcll(m[4]);
-}
-
-// CheckersPlay :36-82 (action must be legal)
-__device__ inline void ru_play(Ru& s, int action) {
-  const uint32_t ft = c_ru_act.ft[action];
-  const int fs = ft & 63, ts = ft >> 6;
-  const uint64_t fb = 1ull << fs, tb = 1ull << ts;
-  const int delta = ((ts >> 3) > (fs >> 3) ? 8 : -8) + ((ts & 7) > (fs & 7) ? 1 : -1);
-  const int dist = abs((ts >> 3) - (fs >> 3));
-  uint64_t path = 0, t = fb;
-  for (int i = 0; i < dist; ++i) { t = delta > 0 ? t << delta : t >> -delta; path |= t; }
-  const bool is_king = (fb & (s.wk | s.bk)) != 0;
-  const bool white_piece = (fb & (s.wp | s.wk)) != 0;
-  const uint64_t cap = path & (s.wp | s.wk | s.bp | s.bk);
-  uint64_t w4 = s.w4;
-  if (cap) {
-    s.wp &= ~cap; s.wk &= ~cap; s.bp &= ~cap; s.bk &= ~cap;
-    // continuation is evaluated from the destination while the piece still stands on its origin (:58-66)
-    const bool white = ru_white(w4);
-    const uint64_t enemy = white ? (s.bp | s.bk) : (s.wp | s.wk);
-    const uint64_t empty = ~(s.wp | s.wk | s.bp | s.bk);
-    bool more = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      uint64_t first = is_king ? ru_sh(ru_fill(tb, empty, k), k) : ru_sh(tb, k);
-      more |= (ru_sh(first & enemy, k) & empty) != 0;
-    }
-    w4 &= ~0xFEull;
-    if (more) w4 |= 2ull | ((uint64_t)(ts >> 3) << 2) | ((uint64_t)(ts & 7) << 5);
-  }
-  // move the piece, promotion (_tryConvertIntoKing :275-280)
-  if (white_piece) {
-    if (is_king) s.wk = (s.wk & ~fb) | tb; else { s.wp &= ~fb; if (ts >= 56) s.wk |= tb; else s.wp |= tb; }
-  } else {
-    if (is_king) s.bk = (s.bk & ~fb) | tb; else { s.bp &= ~fb; if (ts < 8) s.bk |= tb; else s.bp |= tb; }
-  }
-  if (!((w4 >> 1) & 1)) w4 ^= 1;
-  const uint64_t ply = (uint64_t)((ru_ply(w4) + 1) & 0xFFFF);
-  w4 = (w4 & 0xFFull) | (ply << 8) | ((uint64_t)action << 24);
-  s.w4 = w4;
-}
-
-__device__ inline void ru_load(const uint64_t* __restrict__ w, int n, int b, Ru& s) {
-  s.wp = w[0 * (size_t)n + b]; s.wk = w[1 * (size_t)n + b]; s.bp = w[2 * (size_t)n + b];
-  s.bk = w[3 * (size_t)n + b]; s.w4 = w[4 * (size_t)n + b];
-}
-__device__ inline void ru_store(uint64_t* __restrict__ w, int n, int b, const Ru& s) {
-  w[0 * (size_t)n + b] = s.wp; w[1 * (size_t)n + b] = s.wk; w[2 * (size_t)n + b] = s.bp;
-  w[3 * (size_t)n + b] = s.bk; w[4 * (size_t)n + b] = s.w4;
-}
-
-// k-th set bit (0-based, ascending) of a 5-word mask
-__device__ inline int ru_kth(const uint64_t m[5], int kk) {
-  int w = 0; uint64_t sel = 0; bool found = false;
-#pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    int c = __popcll(m[q]);
-    bool here = !found && kk < c;
-    if (here) { w = q; sel = m[q]; found = true; }
-    if (!found) kk -= c;
-  }
-  for (int j = 0; j < kk; ++j) sel &= sel - 1;
-  return w * 64 + __ffsll((long long)sel) - 1;
-}
+using namespace rudev;
 
 // ---- kernels ------------------------------------------------------------------------------------
 __global__ void ru_reset_kernel(uint64_t* w, int n, const uint8_t* __restrict__ which) {

@@ -151,27 +151,45 @@ class SelfPlayEngine : public elfhip_py::Engine {
   }
   ~SelfPlayEngine() override { release(); }
 
-  std::map<std::string, int> getParams() const {  // common/GameFeature.h:225-232
-    return {{"checkers_num_action", gi_.num_actions}, {"checkers_board_size", gi_.board_size},
-            {"checkers_num_future_actions", 1}, {"checkers_num_planes", gi_.num_planes}};
+  std::map<std::string, int> getParams() const {  // common/GameFeature.h:225-232 (ugolki: unprefixed names, :215-222)
+    const std::string p = game_ == ELFHIP_UGOLKI ? "" : "checkers_";
+    return {{p + "num_action", gi_.num_actions}, {p + "board_size", gi_.board_size},
+            {p + "num_future_actions", 1}, {p + "num_planes", gi_.num_planes}};
+  }
+  // russian_checkers prefixes its keys and labels with "checkers_" (russian_checkers/common/GameFeature.h:
+  // 163-209, ClientGameSelfPlay.cc:163-184); both spellings are accepted for every game
+  static std::string base_key(const std::string& k) {
+    static const char* keep[] = {"checkers_predicted_value", "checkers_aug_code", "checkers_num_move"};
+    for (const char* c : keep) if (k == c) return k.substr(9);
+    return k.rfind("checkers_", 0) == 0 ? k.substr(9) : k;
+  }
+  std::vector<SharedMem*>* label(const std::string& name) {
+    auto it = by_label_.find(name);
+    if (it == by_label_.end()) it = by_label_.find("checkers_" + name);
+    return it == by_label_.end() ? nullptr : &it->second;
+  }
+  static AnyP* key(SharedMem* m, const std::string& name) {
+    AnyP* p = m->get(name);
+    return p ? p : m->get("checkers_" + name);
   }
 
-  void describe_key(const std::string& key, FuncMapBase* f) const override {  // GameFeature.h:166-222
+  void describe_key(const std::string& full_key, FuncMapBase* f) const override {  // GameFeature.h:166-222
     auto set = [&](const char* tn, int ts, std::vector<int> ext) { f->type_name = tn; f->type_size = ts; f->sz.v = ext; };
     const int S = gi_.board_size;
+    const std::string key = base_key(full_key);
     if (key == "s") set("float", 4, {gi_.num_planes, S, S});
     else if (key == "pi" || key == "mcts_scores") set("float", 4, {gi_.num_actions});
-    else if (key == "V" || key == "winner" || key == "checkers_predicted_value") set("float", 4, {});
+    else if (key == "V" || key == "winner" || key == "predicted_value") set("float", 4, {});
     else if (key == "a" || key == "rv" || key == "black_ver" || key == "white_ver" || key == "selfplay_ver") set("int64_t", 8, {});
     else if (key == "offline_a") set("int64_t", 8, {go_.checkers_num_future_actions});
-    else if (key == "game_idx" || key == "move_idx" || key == "checkers_aug_code" || key == "checkers_num_move") set("int32_t", 4, {});
-    else throw std::out_of_range("allocateSharedMem: unknown batch key '" + key + "'");
+    else if (key == "game_idx" || key == "move_idx" || key == "aug_code" || key == "num_move") set("int32_t", 4, {});
+    else throw std::out_of_range("allocateSharedMem: unknown batch key '" + full_key + "'");
   }
 
   void on_allocate(SharedMem* m) override { by_label_[m->opts.label].push_back(m); }
 
   void start() override {
-    if (by_label_.find("actor_black") == by_label_.end())
+    if (!label("actor_black"))
       throw std::runtime_error("GameContext: no 'actor_black' batch was allocated (game.py:383-397)");
     const TSOptions& t = co_.mcts_options;
     if (t.pick_method != "most_visited" && t.pick_method != "strongest_prior")
@@ -262,8 +280,8 @@ class SelfPlayEngine : public elfhip_py::Engine {
     hk(hipSetDevice(device_), "hipSetDevice");
     const int k = chunk_n_;
     const size_t A = gi_.num_actions;
-    AnyP* pi = m->get("pi");
-    AnyP* v = m->get("V");
+    AnyP* pi = key(m, "pi");
+    AnyP* v = key(m, "V");
     if (success && pi && v) {
       // ReplyPolicy / ReplyValue (common/GameFeature.h:40-62): rows [0,k) of the caller's tensors
       hk(hipMemcpy2D(d_cpi_, A * 4, pi->row(0), (size_t)pi->strides.at(0), A * 4, k, hipMemcpyHostToDevice), "copy pi");
@@ -322,7 +340,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
     d["rollouts"] = st[0]; d["evals"] = st[1]; d["depth_sum"] = st[2]; d["edge_sum"] = st[3];
     return d;
   }
-  bool two_models() const { return client_.white_ver >= 0 && by_label_.count("actor_white"); }
+  bool two_models() { return client_.white_ver >= 0 && label("actor_white"); }
 
  private:
   enum Phase { BEGIN, SELECT, SERVE, BACKUP, MOVE };
@@ -340,7 +358,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
   }
 
   SharedMem* pick_smem(const std::string& label) {  // num_recv buffers per label are used in turn (game.py:428)
-    auto& v = by_label_.at(label);
+    auto& v = *this->label(label);
     SharedMem* m = v[rr_[label] % v.size()];
     rr_[label] += 1;
     return m;
@@ -352,7 +370,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
     SharedMem* m = pick_smem(white ? "actor_white" : "actor_black");
     const int k = (int)std::min<size_t>((size_t)m->opts.batchsize, end - cursor_);
     const int32_t* idx = (const int32_t*)d_idx_ + cursor_;
-    if (AnyP* s = m->get("s")) {
+    if (AnyP* s = key(m, "s")) {
       // extractGameState -> BoardFeature::extract (GameFeature.h:28-32): leaf planes, one row per state
       ck(elfhip_gather_rows(d_feat_, (long long)feat_row_, idx, k, d_cfeat_, device_, nullptr), "gather s");
       hk(hipMemcpy2D(s->row(0), (size_t)s->strides.at(0), d_cfeat_, feat_row_, feat_row_, k, hipMemcpyDeviceToHost), "copy s");
@@ -414,7 +432,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
         cur_[i].game_idx = i; cur_[i].seq = seq_[i]++; cur_[i].reward = r;
         records_.push_back(std::move(cur_[i]));
         cur_[i] = GameRecord();
-        if (by_label_.count("game_end")) {
+        if (label("game_end")) {
           SharedMem* m = pick_smem("game_end");
           m->effective_batchsize = 1;
           out_.push_back(m);
@@ -489,7 +507,7 @@ PYBIND11_MODULE(ELFGAME_MODULE, m) {
   py::module_::import("_elf");  // Context / SharedMem / TSOptions types live there, as in the reference
   auto ref = py::return_value_policy::reference_internal;
 
-  py::class_<GameContext>(m, "GameContext")
+  py::class_<GameContext>(m, "GameContext", py::module_local())
       .def(py::init<const ContextOptions&, const GameOptions&>())
       .def("ctx", &GameContext::ctx, ref)
       .def("getParams", &GameContext::getParams)
@@ -501,11 +519,12 @@ PYBIND11_MODULE(ELFGAME_MODULE, m) {
       .def("takeRecords", &GameContext::takeRecords)
       .def("searchStats", &GameContext::searchStats);
 
-  py::class_<DistriClient>(m, "DistriClient")
+  py::class_<DistriClient>(m, "DistriClient", py::module_local())
       .def("setRequest", &DistriClient::setRequest, py::arg("black_ver"), py::arg("white_ver"), py::arg("numThreads") = -1)
-      .def("getGameStats", &DistriClient::getGameStats, ref);
+      .def("getGameStats", &DistriClient::getGameStats, ref)
+      .def("getCheckersGameStats", &DistriClient::getGameStats, ref);  // russian_checkers' spelling (pybind/Pybind.cc:38-40)
 
-  py::class_<ContextOptions>(m, "ContextOptions")
+  py::class_<ContextOptions>(m, "ContextOptions", py::module_local())
       .def(py::init<>())
       .def("print", &ContextOptions::print)
       .def_readwrite("job_id", &ContextOptions::job_id)
@@ -515,7 +534,7 @@ PYBIND11_MODULE(ELFGAME_MODULE, m) {
       .def_readwrite("mcts_options", &ContextOptions::mcts_options);
 
 #define GO_FIELD(f) .def_readwrite(#f, &GameOptions::f)
-  py::class_<GameOptions>(m, "GameOptions")
+  py::class_<GameOptions>(m, "GameOptions", py::module_local())
       .def(py::init<>())
       .def("info", &GameOptions::info)
       GO_FIELD(seed) GO_FIELD(checkers_num_future_actions) GO_FIELD(human_plays_for) GO_FIELD(num_games_per_thread)
@@ -528,10 +547,12 @@ PYBIND11_MODULE(ELFGAME_MODULE, m) {
       GO_FIELD(keep_prev_selfplay) GO_FIELD(eval_num_threads) GO_FIELD(expected_num_clients) GO_FIELD(list_files)
       GO_FIELD(server_addr) GO_FIELD(server_id) GO_FIELD(port) GO_FIELD(verbose) GO_FIELD(dump_record_prefix)
       GO_FIELD(selfplay_records_directory) GO_FIELD(eval_records_directory) GO_FIELD(records_buffer_directory)
-      GO_FIELD(time_signature);
+      GO_FIELD(time_signature)
+      .def_readwrite("num_future_actions", &GameOptions::checkers_num_future_actions);  // ugolki's spelling (ugolki/game/GameOptions.h)
 #undef GO_FIELD
+  m.attr("CheckersGameOptions") = m.attr("GameOptions");  // russian_checkers' class name (pybind/Pybind.cc:47-49)
 
-  py::class_<WinRateStats>(m, "WinRateStats")
+  py::class_<WinRateStats>(m, "WinRateStats", py::module_local())
       .def(py::init<>())
       .def_readwrite("black_wins", &WinRateStats::black_wins)
       .def_readwrite("white_wins", &WinRateStats::white_wins)
@@ -539,9 +560,9 @@ PYBIND11_MODULE(ELFGAME_MODULE, m) {
       .def_readwrite("sum_reward", &WinRateStats::sum_reward)
       .def_readwrite("total_games", &WinRateStats::total_games);
 
-  py::class_<GameStats>(m, "GameStats").def("getWinRateStats", &GameStats::getWinRateStats);
+  py::class_<GameStats>(m, "GameStats", py::module_local()).def("getWinRateStats", &GameStats::getWinRateStats);
 
-  py::class_<ClientGameSelfPlay>(m, "ClientGameSelfPlay")
+  py::class_<ClientGameSelfPlay>(m, "ClientGameSelfPlay", py::module_local())
       .def("getCurrentPlayer", &ClientGameSelfPlay::getCurrentPlayer)
       .def("getValidMoves", &ClientGameSelfPlay::getValidMoves)
       // the exported state words of include/elfhip.h instead of the reference's 8x8 int board

@@ -24,6 +24,8 @@
 
 #include "american.h"
 #include "go.h"
+#include "russian.h"
+#include "ugolki.h"
 
 namespace {
 
@@ -87,9 +89,46 @@ void ogomcts_scripted_policy(const uint64_t* state22, uint64_t seed, float* pi36
   scripted(words_hash(state22, GO_STATE_WORDS) ^ seed, GO_ACTIONS, pi362, v);
 }
 
+void orumcts_scripted_policy(const uint64_t* w5, uint64_t seed, float* pi280, float* v) {
+  scripted(words_hash(w5, 5) ^ seed, RU_NUM_ACTIONS, pi280, v);
+}
+void ougmcts_scripted_policy(const uint64_t* w4, uint64_t seed, float* pi418, float* v) {
+  scripted(words_hash(w4, 4) ^ seed, UG_NUM_ACTIONS, pi418, v);
+}
+
 }  // extern "C"
 
 namespace {
+
+// russian_checkers/mcts/CheckersMCTSActor.h:79-335 and ugolki/mcts/MCTSGameActor.h:79-335 are the
+// American actor with other type names; the state is the bare board (no history in the planes)
+struct RuTraits {
+  using State = ru_state;
+  static constexpr int NA = RU_NUM_ACTIONS, MW = 5;
+  static bool flip(const State& s) { return (s.w[4] & 1) == 1; }
+  static bool terminated(const State& s) { return ru_terminated(&s); }
+  static float evaluate(const State& s) { return ru_evaluate(&s); }
+  static void legal(const State& s, uint64_t* m) { ru_legal_mask(&s, m); }
+  static bool forward(State& s, int a) { return ru_forward(&s, a); }
+  static void policy(const State& s, uint64_t seed, float* pi, float* v) { orumcts_scripted_policy(s.w, seed, pi, v); }
+  static bool same(const State& a, const State& b) { return memcmp(a.w, b.w, sizeof(a.w)) == 0; }
+  static void words(const State& s, uint64_t* w) { memcpy(w, s.w, sizeof(s.w)); }
+};
+struct UgTraits {
+  using State = ug_state;
+  static constexpr int NA = UG_NUM_ACTIONS, MW = 7;
+  static bool flip(const State& s) { return (s.w[3] & 1) == 1; }
+  static bool terminated(const State& s) { return ug_terminated(&s); }
+  static float evaluate(const State& s) { return ug_evaluate(&s); }
+  static void legal(const State& s, uint64_t* m) {   // checkMove = TryPlay (ugolki/game/GameState.cc:20-22)
+    for (int i = 0; i < MW; ++i) m[i] = 0;
+    for (int a = 0; a < NA; ++a) if (ug_try_play(&s, a)) m[a >> 6] |= 1ull << (a & 63);
+  }
+  static bool forward(State& s, int a) { return ug_forward(&s, a); }
+  static void policy(const State& s, uint64_t seed, float* pi, float* v) { ougmcts_scripted_policy(s.w, seed, pi, v); }
+  static bool same(const State& a, const State& b) { return memcmp(a.w, b.w, sizeof(a.w)) == 0; }
+  static void words(const State& s, uint64_t* w) { memcpy(w, s.w, sizeof(s.w)); }
+};
 
 struct AmTraits {
   using State = am_game;
@@ -339,6 +378,21 @@ int omcts_run(void* h, const am_game* g, int max_edges, int* n_edges, uint16_t* 
 }
 
 // libstdc++ behaviours exposed for checking the HIP path's explicit emulations (tests only)
+#define ORACLE_MCTS_API(PRE, TRAITS)                                                                              \
+  void* PRE##create(const int* iopt, float c_puct, int policy_kind, uint64_t policy_seed) { return create<TRAITS>(iopt, c_puct, policy_kind, policy_seed); } \
+  void PRE##set_callback(void* h, void (*cb)(const uint64_t*, float*, float*)) { ((Mcts<TRAITS>*)h)->policy_cb = cb; }  \
+  void PRE##set_noise(void* h, float eps, float alpha, unsigned seed) { auto* m = (Mcts<TRAITS>*)h; m->root_epsilon = eps; m->root_alpha = alpha; m->rng.seed(seed); } \
+  void PRE##destroy(void* h) { delete (Mcts<TRAITS>*)h; }                                                          \
+  void PRE##clear(void* h) { ((Mcts<TRAITS>*)h)->clear(); }                                                        \
+  void PRE##advance(void* h, int action) { ((Mcts<TRAITS>*)h)->tree_advance((Action)action); }                      \
+  void PRE##stats(void* h, long* out4) { auto* m = (Mcts<TRAITS>*)h; out4[0] = m->rollouts; out4[1] = m->evals; out4[2] = m->depth_sum; out4[3] = m->edge_sum; } \
+  int PRE##run(void* h, const TRAITS::State* g, int max_edges, int* n_edges, uint16_t* actions, int* visits, float* rewards, \
+               float* priors, int* total_visits, float* root_value, float* best_q) {                               \
+    return run<TRAITS>((Mcts<TRAITS>*)h, g, max_edges, n_edges, actions, visits, rewards, priors, total_visits, root_value, best_q); \
+  }
+ORACLE_MCTS_API(orumcts_, RuTraits)
+ORACLE_MCTS_API(ougmcts_, UgTraits)
+
 void omcts_std_sort_desc(int n, const float* keys, uint16_t* order_out) {
   std::vector<std::pair<Action, float>> v;
   for (int i = 0; i < n; ++i) v.push_back(std::make_pair((Action)i, keys[i]));

@@ -135,6 +135,16 @@ def oracle():
         L.ogomcts_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _i32p, _u16p, _i32p, _f32p, _f32p, _i32p, _f32p, _f32p]
         L.ogomcts_run.restype = C.c_int
         L.ogomcts_scripted_policy.argtypes = [_u64p, C.c_uint64, _f32p, _f32p]
+        for pre in ("orumcts_", "ougmcts_"):
+            getattr(L, pre + "create").argtypes = [_i32p, C.c_float, C.c_int, C.c_uint64]
+            getattr(L, pre + "create").restype = C.c_void_p
+            getattr(L, pre + "destroy").argtypes = [C.c_void_p]
+            getattr(L, pre + "clear").argtypes = [C.c_void_p]
+            getattr(L, pre + "advance").argtypes = [C.c_void_p, C.c_int]
+            getattr(L, pre + "stats").argtypes = [C.c_void_p, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
+            getattr(L, pre + "run").argtypes = [C.c_void_p, C.c_void_p, C.c_int, _i32p, _u16p, _i32p, _f32p, _f32p, _i32p, _f32p, _f32p]
+            getattr(L, pre + "run").restype = C.c_int
+            getattr(L, pre + "scripted_policy").argtypes = [_u64p, C.c_uint64, _f32p, _f32p]
         L.omcts_std_sort_desc.argtypes = [C.c_int, _f32p, _u16p]
         L.omcts_std_umap_order.argtypes = [C.c_int, _u16p, _u16p]
         _oracle = L
@@ -238,6 +248,52 @@ class AmGame:
         out = np.zeros(36 * 64, dtype=np.float32)
         oracle().am_game_features(self.buf, out)
         return out.reshape(36, 8, 8)
+
+
+class FlatGame:
+    """Russian checkers / Ugolki oracle state (bare u64 words; CheckersState / GameState restated in
+    oracle/russian.c, oracle/ugolki.c).  `.buf` is what OracleMcts.run takes."""
+
+    def __init__(self, game):
+        self.pre = dict(russian="ru_", ugolki="ug_")[game]
+        self.nw = dict(russian=5, ugolki=4)[game]
+        self.na = dict(russian=280, ugolki=418)[game]
+        self.mw = dict(russian=5, ugolki=7)[game]
+        self.w = np.zeros(self.nw, dtype=np.uint64)
+        self.reset()
+
+    @property
+    def buf(self):
+        return self.w.ctypes.data_as(C.c_void_p)
+
+    def _f(self, name):
+        return getattr(oracle(), self.pre + name)
+
+    def reset(self):
+        self._f("clear")(self.w)
+
+    def board(self):
+        return self.w.copy()
+
+    def terminated(self):
+        return bool(self._f("terminated")(self.w))
+
+    def forward(self, a):
+        return bool(self._f("forward")(self.w, int(a)))
+
+    def evaluate(self):
+        return float(self._f("evaluate")(self.w))
+
+    def legal(self):
+        m = np.zeros(self.mw, dtype=np.uint64)
+        self._f("legal_mask")(self.w, m)
+        return mask_bits(m, self.na)
+
+    def features(self):
+        planes = 6 if self.pre == "ru_" else 16
+        out = np.zeros(planes * 64, dtype=np.float32)
+        self._f("features")(self.w, out)
+        return out.reshape(planes, 8, 8)
 
 
 def mask_bits(m, n):
@@ -350,8 +406,8 @@ class OracleMcts:
                  unexplored_q_zero=0, root_unexplored_q_zero=0, persistent_tree=1, pick_method=0,
                  policy_kind=0, policy_seed=0, game="american"):
         self.L = oracle()
-        self.pre = "omcts_" if game == "american" else "ogomcts_"
-        self.cap = 64 if game == "american" else 362
+        self.pre = dict(american="omcts_", go="ogomcts_", russian="orumcts_", ugolki="ougmcts_")[game]
+        self.cap = dict(american=64, go=362, russian=128, ugolki=96)[game]
         iopt = np.array([num_rollouts, rollouts_per_batch, virtual_loss, use_prior, unexplored_q_zero,
                          root_unexplored_q_zero, persistent_tree, pick_method], dtype=np.int32)
         self.h = C.c_void_p(getattr(self.L, self.pre + "create")(iopt, c_puct, policy_kind, policy_seed))

@@ -97,3 +97,26 @@ def test_anyp_set_validates_strides():
     bad = ac.GameOptions(); bad.mode = "train"
     with pytest.raises(ValueError):                                  # std::range_error, as the reference's "Unknown mode"
         ac.GameContext(co, bad)                                      # training side is out of scope
+
+
+def test_russian_and_ugolki_modules_use_their_own_names():
+    """russian_checkers prefixes keys / labels / params with "checkers_" and calls its option class
+    CheckersGameOptions (russian_checkers/common/GameFeature.h:163-232, pybind/Pybind.cc:38-49); ugolki uses
+    unprefixed parameter names (ugolki/common/GameFeature.h:215-222)."""
+    import _elfgames_russian_checkers as ru
+    import _elfgames_ugolki as ug
+    co = ru.ContextOptions(); co.num_games = 2
+    go = ru.CheckersGameOptions(); go.mode = "selfplay"
+    GC = ru.GameContext(co, go)
+    assert GC.getParams() == dict(checkers_num_action=280, checkers_board_size=8, checkers_num_future_actions=1, checkers_num_planes=6)
+    ctx = GC.ctx()
+    sm = ctx.allocateSharedMem(ctx.createSharedMemOptions("checkers_actor_black", 4), ["checkers_s", "pi", "V", "a", "rv"])
+    assert sm["checkers_s"].field().sz().vec() == [4, 6, 8, 8] and sm["pi"].field().sz().vec() == [4, 280]
+    assert hasattr(GC.getClient(), "getCheckersGameStats")
+    co = ug.ContextOptions(); co.num_games = 2
+    go = ug.GameOptions(); go.mode = "selfplay"; go.num_future_actions = 1
+    GC = ug.GameContext(co, go)
+    assert GC.getParams() == dict(num_action=418, board_size=8, num_future_actions=1, num_planes=16)
+    ctx = GC.ctx()
+    sm = ctx.allocateSharedMem(ctx.createSharedMemOptions("actor_black", 4), ["s", "pi"])
+    assert sm["s"].field().sz().vec() == [4, 16, 8, 8] and sm["pi"].field().sz().vec() == [4, 418]

@@ -110,3 +110,71 @@ def test_facade_failed_step_keeps_running():
     with pytest.raises(RuntimeError):
         ctx.step()                                          # nothing is out
     w.stop()
+
+
+@pytest.mark.parametrize("game", ["russian", "ugolki"])
+def test_facade_other_games_match_oracle_search(game):
+    """_elfgames_russian_checkers / _elfgames_ugolki: one game each through wait/step with a scripted
+    Python actor; the recorded moves equal the oracle search driven by the same scripted policy."""
+    import importlib
+    from tests import _oracle
+    from tests._oracle import FlatGame, OracleMcts
+    L = _oracle.oracle()
+    mod = importlib.import_module("_elfgames_russian_checkers" if game == "russian" else "_elfgames_ugolki")
+    pre = "checkers_" if game == "russian" else ""
+    na, nw, planes = (280, 5, 6) if game == "russian" else (418, 4, 16)
+    co = mod.ContextOptions()
+    co.num_games, co.batchsize = 3, 7
+    m = co.mcts_options
+    m.num_threads, m.num_rollouts_per_thread, m.num_rollouts_per_batch, m.virtual_loss, m.alg_opt.c_puct = 1, 32, 4, 1, 1.5
+    go = (mod.CheckersGameOptions if game == "russian" else mod.GameOptions)()
+    go.mode, go.policy_distri_cutoff = "selfplay", 0
+    GC = mod.GameContext(co, go)
+    desc = {"game_end": dict(batchsize=1),
+            pre + "actor_black": dict(input=[pre + "s"], reply=["pi", "V", "a", "rv"], batchsize=7)}
+    w = _gcwrapper.Wrapper(GC, 7, desc, num_recv=2)
+    scripted = getattr(L, ("orumcts_" if game == "russian" else "ougmcts_") + "scripted_policy")
+
+    # the scripted policy is keyed on the state words, which the actor does not see: key it on the planes
+    # instead, on both sides (oracle callback below gets the state and computes the planes first)
+    def policy_from_planes(f):
+        h = np.frombuffer(np.packbits(f.astype(np.uint8).reshape(-1)).tobytes().ljust(8 * 32, b"\0")[: 8 * 32], dtype=np.uint64)
+        pi = np.zeros(na, dtype=np.float32); v = np.zeros(1, dtype=np.float32)
+        scripted(np.ascontiguousarray(h[:nw]) ^ np.ascontiguousarray(h[nw:2 * nw]), 9, pi, v)
+        return pi, float(v[0])
+
+    def actor(batch, bs):
+        s = batch[pre + "s"]
+        assert s.shape == (bs, planes, 8, 8)
+        out = [policy_from_planes(s[k]) for k in range(bs)]
+        return dict(pi=np.stack([o[0] for o in out]), V=np.array([o[1] for o in out], dtype=np.float32),
+                    a=np.zeros(bs, dtype=np.int64), rv=np.zeros(bs, dtype=np.int64))
+
+    w.reg_callback(pre + "actor_black", actor)
+    ends = []
+    w.reg_callback("game_end", lambda batch, bs: ends.append(1))
+    w.start()
+    for _ in range(60000):
+        w.run()
+        if len(ends) >= 3:
+            break
+    recs = [r for r in GC.takeRecords() if r["seq"] == 0]
+    assert len(recs) == 3
+    # oracle: same search with the callback policy (policy_kind 2)
+    g = FlatGame(game)
+    om = OracleMcts(policy_kind=2, num_rollouts=32, rollouts_per_batch=4, virtual_loss=1, c_puct=1.5, game=game)
+
+    def cb(words):
+        leaf = FlatGame(game); leaf.w[:] = words[:nw]
+        return policy_from_planes(leaf.features())
+    om.set_callback(cb, nw, na)
+    moves = []
+    while not g.terminated():
+        r = om.run(g)
+        if not r["edges"]:
+            break
+        moves.append(r["best"]); assert g.forward(r["best"]); om.advance(r["best"])
+    for r in recs:
+        assert list(r["moves"]) == moves
+        assert r["reward"] == g.evaluate()
+    w.stop()
