@@ -129,8 +129,13 @@ go_playout_kernel(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t s
   if (valid) { go_load(d, b, s); gen = d.gen[b]; }
   const uint64_t key = seed + (first_id + (uint64_t)b) * ELF_GOLDEN + step_base;
   unsigned long long moves = 0;
+#ifdef GO_PROF
+  if (threadIdx.x < 32) s_go_prof[threadIdx.x] = 0;
+  __syncthreads();
+#endif
 #pragma unroll 1
   for (int step = 0; step < nply; ++step) {
+    PROF_T0;
     const bool term = go_terminated(s);
     if (valid && term) {  // reset in place, 0 moves
       go_clear(s);
@@ -155,9 +160,15 @@ go_playout_kernel(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t s
       for (int j = 0; j < k; ++j) rowbits &= rowbits - 1;
       a = row * 19 + (uint32_t)(__ffs(rowbits) - 1);
     }
+    PROF_ADD(4);
     go_forward(s, act, a, tab, gen, z);
+    PROF_ADD(5);
     moves += act ? 1 : 0;
   }
+#ifdef GO_PROF
+  __syncthreads();
+  if (threadIdx.x < 32) atomicAdd(&g_go_prof[threadIdx.x], s_go_prof[threadIdx.x]);
+#endif
   if (valid) { go_store(d, b, s); d.gen[b] = gen; go_hist_set_single(d, b, s); }  // playouts keep no plane history
   if (moves_out) {
     for (int o = 32; o > 0; o >>= 1) moves += __shfl_down(moves, o);
@@ -330,3 +341,11 @@ struct GoSlab : BoardSlab {
 }  // namespace
 
 BoardSlab* elfhip_make_go19() { return new GoSlab(); }
+
+#ifdef GO_PROF
+extern "C" int elfhip_debug_go_prof(unsigned long long* h_out32, int reset) {
+  if (h_out32 && hipMemcpyFromSymbol(h_out32, HIP_SYMBOL(godev::g_go_prof), 32 * 8) != hipSuccess) return -2;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(godev::g_go_prof), z, 32 * 8) != hipSuccess) return -2; }
+  return 0;
+}
+#endif

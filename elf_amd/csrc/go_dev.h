@@ -5,6 +5,19 @@
 
 namespace godev {
 
+#ifdef GO_PROF
+// timing-only instrumentation (never in the product build): per-wave cycle counts by section
+__device__ unsigned long long g_go_prof[32];
+static __shared__ unsigned long long s_go_prof[32];
+#define PROF_T0 unsigned long long _t0 = clock64()
+#define PROF_ADD(k) do { unsigned long long _t1 = clock64(); if (threadIdx.x == 0) s_go_prof[k] += _t1 - _t0; _t0 = clock64(); } while (0)
+#define PROF_INC(k, v) do { if (threadIdx.x == 0) s_go_prof[k] += (v); } while (0)
+#else
+#define PROF_T0
+#define PROF_ADD(k)
+#define PROF_INC(k, v)
+#endif
+
 constexpr int GN = 19;
 constexpr uint32_t FULL = 0x7FFFFu;
 constexpr int GO_POINTS = 361;
@@ -12,7 +25,8 @@ constexpr int GO_PASS = 361;
 constexpr int GO_MAX_PLY = 722;
 constexpr uint32_t NO_POINT = 0xFFFFu;
 constexpr uint64_t GO_ZSEED = 0x60BA7D5EEDull;
-constexpr int TAB_SLOTS = 1024;
+constexpr int TAB_SLOTS = 2048;                  // superko set entries per board (a game has <= 723 positions)
+constexpr int TAB_BUCKETS = TAB_SLOTS / 4;        // buckets of 4 x {hash, generation} = one 64-byte line
 constexpr int GO_WORDS = 22;
 constexpr int NROWW = 57;  // B[19], W[19], AT[19]
 
@@ -40,8 +54,10 @@ __device__ inline void go_clear(GoS& s) {
 // Alternating down/up sweeps, in place; exits when no lane of the wave changed.
 __device__ inline void go_fill(uint32_t (&F)[GN], const uint32_t (&M)[GN]) {
   // A complete sweep that changes nothing proves a fixpoint, so test after every sweep.
+  PROF_INC(20, 1);
   for (;;) {
     uint32_t chg = 0;
+    PROF_INC(21, 1);
     ROWS(i) {
       uint32_t up = i > 0 ? F[i > 0 ? i - 1 : 0] : 0u, dn = i < GN - 1 ? F[i < GN - 1 ? i + 1 : 0] : 0u;
       uint32_t t = (F[i] | up | dn) & M[i];
@@ -52,6 +68,7 @@ __device__ inline void go_fill(uint32_t (&F)[GN], const uint32_t (&M)[GN]) {
     }
     if (!__any(chg != 0)) break;
     chg = 0;
+    PROF_INC(21, 1);
     ROWS_REV(i) {
       uint32_t up = i > 0 ? F[i > 0 ? i - 1 : 0] : 0u, dn = i < GN - 1 ? F[i < GN - 1 ? i + 1 : 0] : 0u;
       uint32_t t = (F[i] | up | dn) & M[i];
@@ -102,69 +119,161 @@ __device__ inline int go_legal_rows(const GoS& s, uint32_t (&L)[GN]) {
   return n;
 }
 
+// One growth pass over the whole board, in place: rows in ascending (DOWN) or descending order, each
+// row taking its already-updated predecessor, so the set spreads all the way along the sweep
+// direction, one row against it and two points sideways.
+//   inc  = bits that were added (0 <=> F was already a union of complete M-components)
+//   nlib = distinct empty points adjacent to the stones the pass looked at: a lower bound of the
+//          group's liberties, exact when inc == 0 (E = empty points)
+// ~15 VALU instructions per row; the evaluation rides on the neighbourhood the growth needs anyway.
+template <bool EVAL, bool DOWN>
+__device__ inline void go_grow(uint32_t (&F)[GN], const uint32_t (&M)[GN], const uint32_t (&E)[GN], uint32_t& inc, int& nlib) {
+  inc = 0; nlib = 0;
+  uint32_t prev = 0;  // the row before this one in sweep order, after its update
+#pragma unroll
+  for (int k = 0; k < GN; ++k) {
+    const int i = DOWN ? k : GN - 1 - k;
+    const int j = DOWN ? i + 1 : i - 1;                       // the row after this one: not updated yet
+    const uint32_t f = F[i];
+    const uint32_t nx = (j >= 0 && j < GN) ? F[(j >= 0 && j < GN) ? j : 0] : 0u;
+    const uint32_t nb = (f << 1) | (f >> 1) | prev | nx;
+    uint32_t g = nb & M[i];
+    g = (g | (g << 1) | (g >> 1)) & M[i];
+    inc |= g & ~f;
+    if (EVAL) nlib += __popc(nb & E[i]);
+    prev = f | g;
+    F[i] = prev;
+  }
+}
+
+// grow F (subset of M) to the complete M-components it touches; every lane of the wave takes part
+__device__ inline void go_fill_complete(uint32_t (&F)[GN], const uint32_t (&M)[GN]) {
+  PROF_INC(20, 1);
+  for (;;) {
+    uint32_t inc; int nl;
+    PROF_INC(21, 1);
+    go_grow<false, true>(F, M, M, inc, nl);
+    if (!__any(inc != 0)) break;
+    PROF_INC(21, 1);
+    go_grow<false, false>(F, M, M, inc, nl);
+    if (!__any(inc != 0)) break;
+  }
+}
+
+// Liberty status of the group that contains the seed F (subset of M), after a move next to it:
+// AT must end up set on the whole group iff it has exactly one liberty.  The group is only grown as
+// far as the answer needs: as soon as the part found so far already touches two empty points the
+// group cannot be in atari, and if none of it carried an AT bit before (need_full == false) there is
+// nothing to rewrite, so the lane is done without ever seeing the rest of a large chain.  Lanes that
+// must set or clear bits (atari, or a group leaving atari) grow to the complete group.
+// size / libs are exact when the group was completed; libs = 2 (meaning "at least two") otherwise.
+__device__ inline void go_group_status(GoS& s, uint32_t (&F)[GN], const uint32_t (&M)[GN], const uint32_t (&E)[GN],
+                                       bool need_full, int& size, int& libs) {
+  bool fin = false, noop = false;
+  int nlib = 0;
+  PROF_INC(20, 1);
+  for (;;) {
+    uint32_t inc;
+    PROF_INC(21, 1);
+    go_grow<true, true>(F, M, E, inc, nlib);
+    if (!fin) {
+      if (inc == 0) fin = true;
+      else if (nlib >= 2 && !need_full) { fin = true; noop = true; }
+    }
+    if (!__any(!fin)) break;
+    PROF_INC(21, 1);
+    go_grow<true, false>(F, M, E, inc, nlib);
+    if (!fin) {
+      if (inc == 0) fin = true;
+      else if (nlib >= 2 && !need_full) { fin = true; noop = true; }
+    }
+    if (!__any(!fin)) break;
+  }
+  // a finished-by-completion lane re-evaluates the same complete F on later passes: nlib stays exact
+  size = 0;
+  if (!noop) {
+    const bool in_atari = nlib == 1;
+    ROWS(i) { s.AT[i] = (s.AT[i] & ~F[i]) | (in_atari ? F[i] : 0u); size += __popc(F[i]); }
+    libs = nlib;
+  } else {
+    libs = 2;
+  }
+}
+
 // Play a stone for the side to move at row r / column bit `bit` (must be legal) when act is true;
 // lanes with act == false run the same instructions with empty seeds and change nothing.
 // Updates stones, AT, hash, ko, capP.  z = Zobrist table in LDS ([colour*361 + point]).
-__device__ inline void go_place(GoS& s, bool act, uint32_t r, uint32_t bit, const uint64_t* z) {
+// hash_ready(hash) is called once the new position's hash is final (captures and the stone are in),
+// before the liberty bookkeeping: the caller may start loading whatever the superko test will need.
+template <class HR>
+__device__ inline void go_place(GoS& s, bool act, uint32_t r, uint32_t bit, const uint64_t* z, HR hash_ready) {
   if (!act) bit = 0;
-  uint32_t C[GN];  // captured stones
   uint32_t ncap = 0, cap_pt = 0;
-  uint32_t own_size = 0, own_libs = 0;
-  // jobs: 0 capture (opp groups in atari next to the stone), 1 release (own atari groups next to
-  // captured stones gain liberties), 2 own group of the new stone, 3..6 opp neighbour groups
+  PROF_T0;
+  uint32_t F[GN];
+  // ---- captures: opponent groups in atari next to the stone (their one liberty is this point) ----
+  bool own_at_nbr = false;  // an own group in atari touches the point: it merges and must be rewritten
+  ROWS(i) {
+    const uint32_t s0 = (uint32_t)i == r ? bit : 0u, su = (uint32_t)i + 1 == r ? bit : 0u, sd = (uint32_t)i == r + 1 ? bit : 0u;
+    const uint32_t nbr = ((s0 << 1) | (s0 >> 1) | su | sd) & FULL;
+    F[i] = nbr & s.Q[i] & s.AT[i];
+    own_at_nbr = own_at_nbr || (nbr & s.P[i] & s.AT[i]) != 0;
+  }
+  const bool any_cap = go_any_rows(F);
+  PROF_ADD(0);
+  if (any_cap) {
+    PROF_INC(10, 1);
+    go_fill_complete(F, s.Q);
+    PROF_ADD(1);
+    uint32_t R[GN];
+    ROWS(i) {
+      s.Q[i] &= ~F[i];
+      s.AT[i] &= ~F[i];
+      ncap += __popc(F[i]);
+      if (F[i]) cap_pt = i * 19 + (__ffs(F[i]) - 1);
+      uint32_t m = F[i];
+      while (__any(m != 0)) {
+        if (m) { int c = __ffs(m) - 1; m &= m - 1; s.hash ^= z[(s.tm ^ 1) * GO_POINTS + i * 19 + c]; }
+      }
+    }
+    // own groups in atari next to the captured stones gain a liberty: they leave AT
+    ROWS(i) R[i] = NBR(F, i) & s.P[i] & s.AT[i];
+    PROF_ADD(2);
+    if (go_any_rows(R)) {
+      PROF_INC(11, 1);
+      go_fill_complete(R, s.P);
+      ROWS(i) s.AT[i] &= ~R[i];
+      PROF_ADD(1);
+    }
+  }
+  // ---- the stone itself ----
+  uint32_t E[GN];
+  ROWS(i) {
+    const uint32_t s0 = (uint32_t)i == r ? bit : 0u;
+    s.P[i] |= s0;
+    F[i] = s0;
+    E[i] = ~(s.P[i] | s.Q[i]) & FULL;
+  }
+  if (act) { s.hash ^= z[s.tm * GO_POINTS + r * 19 + (__ffs(bit) - 1)]; hash_ready(s.hash); }
+  int own_size = 0, own_libs = 0;
+  PROF_ADD(0);
+  PROF_INC(12, 1);
+  go_group_status(s, F, s.P, E, own_at_nbr, own_size, own_libs);
+  PROF_ADD(3);
+  // ---- the (up to four) opponent groups that lost this liberty.  None of them carries an AT bit:
+  //      a neighbour in atari was just captured. ----
 #pragma unroll 1
-  for (int job = 0; job < 7; ++job) {
-    uint32_t F[GN];
-    const bool onP = (job == 1 || job == 2);
-    if (job == 0) {
-      ROWS(i) {
-        uint32_t s0 = (uint32_t)i == r ? bit : 0u, su = (uint32_t)i + 1 == r ? bit : 0u, sd = (uint32_t)i == r + 1 ? bit : 0u;
-        F[i] = (((s0 << 1) | (s0 >> 1) | su | sd) & FULL) & s.Q[i] & s.AT[i];
-      }
-    } else if (job == 1) {
-      if (!__any(ncap != 0)) continue;
-      ROWS(i) F[i] = NBR(C, i) & s.P[i] & s.AT[i];
-    } else if (job == 2) {
-      ROWS(i) { uint32_t s0 = (uint32_t)i == r ? bit : 0u; s.P[i] |= s0; F[i] = s0; }
-      if (act) s.hash ^= z[s.tm * GO_POINTS + r * 19 + (__ffs(bit) - 1)];
-    } else {
-      const int d = job - 3;  // 0 up, 1 down, 2 left, 3 right
-      ROWS(i) {
-        uint32_t sd;
-        if (d == 0) sd = (uint32_t)i + 1 == r ? bit : 0u;
-        else if (d == 1) sd = (uint32_t)i == r + 1 ? bit : 0u;
-        else if (d == 2) sd = (uint32_t)i == r ? (bit >> 1) : 0u;
-        else sd = (uint32_t)i == r ? ((bit << 1) & FULL) : 0u;
-        F[i] = sd & s.Q[i];
-      }
-    }
-    if (!go_any_rows(F)) {
-      if (job == 0) { ROWS(i) C[i] = 0; }
-      continue;
-    }
-    if (onP) go_fill(F, s.P); else go_fill(F, s.Q);
-    if (job == 0) {
-      ROWS(i) {
-        C[i] = F[i];
-        s.Q[i] &= ~F[i];
-        s.AT[i] &= ~F[i];
-        ncap += __popc(F[i]);
-        if (F[i]) cap_pt = i * 19 + (__ffs(F[i]) - 1);
-        uint32_t m = F[i];
-        while (__any(m != 0)) {
-          if (m) { int c = __ffs(m) - 1; m &= m - 1; s.hash ^= z[(s.tm ^ 1) * GO_POINTS + i * 19 + c]; }
-        }
-      }
-    } else if (job == 1) {
-      ROWS(i) s.AT[i] &= ~F[i];
-    } else {
-      int libs = go_libs(F, s);
-      go_set_at(s, F, libs == 1);
-      if (job == 2) {
-        own_libs = libs;
-        ROWS(i) own_size += __popc(F[i]);
-      }
-    }
+  for (int d = 0; d < 4; ++d) {  // 0 up, 1 down, 2 left, 3 right
+    const uint32_t rr = d == 0 ? r - 1u : d == 1 ? r + 1u : r;      // r - 1 wraps to a row that does not exist
+    const uint32_t bb = d == 2 ? (bit >> 1) : d == 3 ? ((bit << 1) & FULL) : bit;
+    ROWS(i) F[i] = ((uint32_t)i == rr ? bb : 0u) & s.Q[i];
+    const bool any = go_any_rows(F);
+    PROF_ADD(0);
+    if (!any) continue;
+    PROF_INC(13 + d, 1);
+    int sz, lb;
+    go_group_status(s, F, s.Q, E, false, sz, lb);
+    PROF_ADD(3);
   }
   if (act) {
     s.capP += ncap;
@@ -172,14 +281,40 @@ __device__ inline void go_place(GoS& s, bool act, uint32_t r, uint32_t bit, cons
   }
 }
 
-// positional superko set: returns 1 if h was already present, else inserts it
-__device__ inline uint32_t go_table_test_and_insert(ulonglong2* tab, uint64_t gen, uint64_t h) {
-  uint32_t idx = (uint32_t)(h >> 40) & (TAB_SLOTS - 1);
-  for (int probe = 0; probe < TAB_SLOTS; ++probe) {
-    ulonglong2 e = tab[idx];
-    if (e.y != gen) { tab[idx] = make_ulonglong2(h, gen); return 0; }
-    if (e.x == h) return 1;
-    idx = (idx + 1) & (TAB_SLOTS - 1);
+// Positional superko set of one game: open addressing over 64-byte buckets of four {hash, game
+// generation} entries; an entry of another generation is free (reset = generation + 1, O(1)).  A key
+// lives in the first bucket of its probe sequence that had a free entry when it was inserted, so a
+// lookup ends at the first bucket that holds the key or still has a free entry.  One probe = one
+// memory round trip for four entries; the first bucket can be loaded as soon as the hash is known
+// (go_place's prefetch hook) and checked after the liberty bookkeeping has hidden its latency.
+struct GoBucket { ulonglong2 e[4]; };
+__device__ inline uint32_t go_bucket_of(uint64_t h) { return (uint32_t)(h >> 40) & (TAB_BUCKETS - 1); }
+__device__ inline void go_bucket_load(const ulonglong2* tab, uint32_t b, GoBucket& k) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) k.e[j] = tab[(size_t)b * 4 + j];
+}
+// 1: h present; 0: absent and entry `free` of the bucket is free; -1: bucket full of other keys
+__device__ inline int go_bucket_probe(const GoBucket& k, uint64_t gen, uint64_t h, int& free) {
+  int r = -1; free = 0;
+#pragma unroll
+  for (int j = 3; j >= 0; --j) {
+    const bool live = k.e[j].y == gen;
+    if (!live) { r = r == 1 ? 1 : 0; free = j; }
+    if (live && k.e[j].x == h) r = 1;
+  }
+  return r;
+}
+// returns 1 if h was already present, else inserts it.  first = the prefetched bucket go_bucket_of(h), or null
+__device__ inline uint32_t go_table_test_and_insert(ulonglong2* tab, uint64_t gen, uint64_t h, const GoBucket* first = nullptr) {
+  uint32_t b = go_bucket_of(h);
+  for (int probe = 0; probe < TAB_BUCKETS; ++probe) {
+    GoBucket k;
+    if (probe == 0 && first) k = *first; else go_bucket_load(tab, b, k);
+    int free;
+    const int r = go_bucket_probe(k, gen, h, free);
+    if (r == 1) return 1;
+    if (r == 0) { tab[(size_t)b * 4 + free] = make_ulonglong2(h, gen); return 0; }
+    b = (b + 1) & (TAB_BUCKETS - 1);
   }
   return 0;
 }
@@ -187,12 +322,13 @@ __device__ inline uint32_t go_table_test_and_insert(ulonglong2* tab, uint64_t ge
 // One full forward() for this lane's board: a = point index or GO_PASS; act = lane takes part.
 // The caller has verified legality.  Swaps P/Q so that P is again the side to move.
 // superko(hash) -> 0/1 decides whether the new position repeats an earlier one of this game.
-template <class SK>
-__device__ inline void go_forward_t(GoS& s, bool act, uint32_t a, const uint64_t* z, SK superko) {
+template <class HR, class SK>
+__device__ inline void go_forward_t(GoS& s, bool act, uint32_t a, const uint64_t* z, HR hash_ready, SK superko) {
   const bool is_pass = a >= GO_POINTS;
   const bool pt_move = act && !is_pass;
   const uint32_t r = pt_move ? a / 19u : 0u, bit = pt_move ? 1u << (a % 19u) : 0u;
-  go_place(s, pt_move, r, bit, z);
+  go_place(s, pt_move, r, bit, z, hash_ready);
+  PROF_T0;
   if (act) {
     if (is_pass) { s.passes += 1; s.ko = NO_POINT; }
     else { s.passes = 0; s.superko = superko(s.hash); }
@@ -200,10 +336,13 @@ __device__ inline void go_forward_t(GoS& s, bool act, uint32_t a, const uint64_t
     ROWS(i) { uint32_t t = s.P[i]; s.P[i] = s.Q[i]; s.Q[i] = t; }
     uint32_t t = s.capP; s.capP = s.capQ; s.capQ = t;
   }
+  PROF_ADD(6);
 }
 // the board slab's version: the game's own superko table, test and insert
 __device__ inline void go_forward(GoS& s, bool act, uint32_t a, ulonglong2* tab, uint64_t gen, const uint64_t* z) {
-  go_forward_t(s, act, a, z, [&](uint64_t h) { return go_table_test_and_insert(tab, gen, h); });
+  GoBucket first;
+  go_forward_t(s, act, a, z, [&](uint64_t h) { go_bucket_load(tab, go_bucket_of(h), first); },
+               [&](uint64_t h) { return go_table_test_and_insert(tab, gen, h, &first); });
 }
 
 // ---- SoA storage: rows [57][n] (B, W, AT), meta [4][n], hash [n], gen [n], table [n][1024] -------
@@ -304,12 +443,14 @@ __device__ inline void go_pack_mask(const uint32_t (&L)[GN], bool alive, uint64_
 
 // read-only membership test of the positional-superko set (tree search: a node must not insert)
 __device__ inline uint32_t go_table_contains(const ulonglong2* tab, uint64_t gen, uint64_t h) {
-  uint32_t idx = (uint32_t)(h >> 40) & (TAB_SLOTS - 1);
-  for (int probe = 0; probe < TAB_SLOTS; ++probe) {
-    ulonglong2 e = tab[idx];
-    if (e.y != gen) return 0;
-    if (e.x == h) return 1;
-    idx = (idx + 1) & (TAB_SLOTS - 1);
+  uint32_t b = go_bucket_of(h);
+  for (int probe = 0; probe < TAB_BUCKETS; ++probe) {
+    GoBucket k;
+    go_bucket_load(tab, b, k);
+    int free;
+    const int r = go_bucket_probe(k, gen, h, free);
+    if (r >= 0) return (uint32_t)r;
+    b = (b + 1) & (TAB_BUCKETS - 1);
   }
   return 0;
 }

@@ -147,7 +147,7 @@ go_tree_expand_kernel(TreeDev d, Opt o, GoDev g, const uint64_t* __restrict__ gz
   // in the game's history (the slab's table, read only) or on the path from the root to the parent.
   const ulonglong2* tab = g.table + (size_t)t * TAB_SLOTS;
   const uint64_t gen = g.gen[t];
-  go_forward_t(s, pending, a, z, [&](uint64_t h) -> uint32_t {
+  go_forward_t(s, pending, a, z, [](uint64_t) {}, [&](uint64_t h) -> uint32_t {
     if (go_table_contains(tab, gen, h)) return 1u;
     for (int p = parent; p >= 0; p = tv.parent[p]) {
       const uint32_t* w = tv.state + (size_t)p * GO_SW;
