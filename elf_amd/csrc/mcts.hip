@@ -136,6 +136,20 @@ __device__ inline void emit_leaf_features(const AmExtra& x, const TV& tv, int t,
 // MODE 0: fused uniform-policy search (all batches of one run() in one launch)
 // MODE 1: select one batch, emit leaves for an external evaluator
 // MODE 2: expand locked leaves from the evaluator's (pi, V) and back up the batch
+#ifdef MCTS_PROF
+__device__ unsigned long long g_mcts_prof[8];
+#define MP_T0 unsigned long long _t0 = clock64()
+#define MP_ADD(k) do { unsigned long long _t1 = clock64(); if (lane == 0) atomicAdd(&g_mcts_prof[k], _t1 - _t0); _t0 = clock64(); } while (0)
+extern "C" int elfhip_debug_mcts_prof(unsigned long long* h8, int reset) {
+  if (h8 && hipMemcpyFromSymbol(h8, HIP_SYMBOL(g_mcts_prof), 64) != hipSuccess) return -2;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mcts_prof), z, 64) != hipSuccess) return -2; }
+  return 0;
+}
+#else
+#define MP_T0
+#define MP_ADD(k)
+#endif
+
 template <int MODE>
 __global__ void __launch_bounds__(64)
 mcts_search_kernel(TreeDev d, AmExtra x, Opt o, uint64_t* __restrict__ leaf_states, float* __restrict__ leaf_feat,
@@ -151,6 +165,7 @@ mcts_search_kernel(TreeDev d, AmExtra x, Opt o, uint64_t* __restrict__ leaf_stat
   unsigned long long rollouts = 0, evals = 0, depth_sum = 0, edge_sum = 0;
   const int nbatch = MODE == 0 ? (o.R + o.B - 1) / o.B : 1;
   for (int batch = 0; batch < nbatch && !flags; ++batch) {
+    MP_T0;
     if (MODE != 2) {
       for (int j = 0; j < o.B; ++j) {
         int depth = 0;
@@ -176,6 +191,7 @@ mcts_search_kernel(TreeDev d, AmExtra x, Opt o, uint64_t* __restrict__ leaf_stat
         }
       }
       __syncthreads();
+      MP_ADD(0);
     } else {
       if (lane < o.B) { s_leaf[lane] = d.leaf[(size_t)t * o.B + lane]; s_locked[lane] = d.locked[(size_t)t * o.B + lane]; }
       __syncthreads();
@@ -187,8 +203,10 @@ mcts_search_kernel(TreeDev d, AmExtra x, Opt o, uint64_t* __restrict__ leaf_stat
         expand_leaf(d, tv, s_leaf[j], MODE == 2 ? pi + slot * NA : nullptr, MODE == 2 ? vin[slot] : 0.0f, lane, ne, flags,
                     S, evals, edge_sum);
       }
+      MP_ADD(1);
       backup_batch(d, tv, o, t, s_leaf);
       __syncthreads();
+      MP_ADD(2);
     }
   }
   if (lane == 0) {

@@ -89,15 +89,16 @@ __device__ inline int select_one(const TreeDev& d, TV& tv, const Opt& o, int t, 
     const float pq = tv.parentQ[node];
     const int nv = tv.visits[node];
     const double sq = sqrt((double)(nv + 1));
-    float best = -INFINITY; int bestj = 0x7FFFFFFF;
+    float best = -INFINITY; int bestj = 0x7FFFFFFF, bestc = -1;
     float total_uq = 0.f; int total_cnt = 0;
     for (int base = 0; base < ne; base += 64) {
       const int j = base + lane;
       const bool ok = j < ne;
-      float score = -INFINITY, uq = 0.f; int counted = 0;
+      float score = -INFINITY, uq = 0.f; int counted = 0, cj = -1;
       if (ok) {  // EdgeInfo::getScore tree_search_base.h:175-201
         const float prior = tv.ep[eb + j], reward = tv.er[eb + j], vloss = tv.el[eb + j];
         const int visits = tv.ev[eb + j];
+        cj = tv.ec[eb + j];  // fetched with the other edge fields: saves a dependent round trip after the argmax
         float r = flip ? -reward : reward;
         r -= vloss;
         const int nvl = (int)((float)visits + vloss);
@@ -107,20 +108,32 @@ __device__ inline int select_one(const TreeDev& d, TV& tv, const Opt& o, int t, 
         score = o.use_prior ? (u * o.c_puct + q) : q;
         counted = nvl != 0;
       }
-      // first strict maximum in edge order == max score, lowest index on ties
-      float s = score; int sj = ok ? j : 0x7FFFFFFF;
+      const unsigned long long cmask = __ballot(counted != 0);
+      if (ne <= 16) {
+        // few edges (checkers): walk them in edge order on wave-uniform values read straight out of the
+        // lanes' registers - the reference's own loop, no cross-lane reduction
+        for (int k = 0; k < ne; ++k) {
+          const float sk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(score), k));
+          if (sk > best || bestj == 0x7FFFFFFF) { best = sk; bestj = k; }
+          if ((cmask >> k) & 1) { total_uq += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uq), k)); total_cnt++; }
+        }
+        bestc = __builtin_amdgcn_readlane(cj, bestj == 0x7FFFFFFF ? 0 : bestj);
+      } else {
+        // first strict maximum in edge order == max score, lowest index on ties
+        float s = score; int sj = ok ? j : 0x7FFFFFFF, sc = cj;
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        float s2 = __shfl_xor(s, off); int j2 = __shfl_xor(sj, off);
-        if (s2 > s || (s2 == s && j2 < sj)) { s = s2; sj = j2; }
-      }
-      if (s > best || (s == best && sj < bestj)) { best = s; bestj = sj; }
-      // total_unsigned_q is a float sum in edge order: keep the order (only counted edges add)
-      unsigned long long cm = __ballot(counted != 0);
-      while (cm) {
-        const int k = __ffsll((long long)cm) - 1;
-        cm &= cm - 1;
-        total_uq += __shfl(uq, k); total_cnt++;
+        for (int off = 32; off > 0; off >>= 1) {
+          float s2 = __shfl_xor(s, off); int j2 = __shfl_xor(sj, off), c2 = __shfl_xor(sc, off);
+          if (s2 > s || (s2 == s && j2 < sj)) { s = s2; sj = j2; sc = c2; }
+        }
+        if (s > best || (s == best && sj < bestj)) { best = s; bestj = sj; bestc = sc; }
+        // total_unsigned_q is a float sum in edge order: keep the order (only counted edges add)
+        unsigned long long cm = cmask;
+        while (cm) {
+          const int k = __ffsll((long long)cm) - 1;
+          cm &= cm - 1;
+          total_uq += __shfl(uq, k); total_cnt++;
+        }
       }
     }
     mq = (pq + total_uq) / (float)(total_cnt + 1);  // tree_search_node.h:240-241
@@ -128,7 +141,7 @@ __device__ inline int select_one(const TreeDev& d, TV& tv, const Opt& o, int t, 
     const int e = eb + bestj;
     if (o.vl > 0) tv.el[e] = tv.el[e] + (float)o.vl;  // addVirtualLoss :246-264
     tn[depth] = (uint16_t)node; te[depth] = (uint16_t)bestj;
-    int child = tv.ec[e];
+    int child = bestc;
     if (child < 0) {  // followEdge :295-317 + allocateState tree_search.h:209-224
       if (nn >= d.max_nodes) { flags |= FLAG_NODE_OVERFLOW; ++depth; break; }
       child = nn++;
@@ -172,15 +185,28 @@ __device__ inline void expand_edges(const TreeDev& d, TV& tv, int leaf, bool ter
       for (int i = lane; i < NA; i += 64) { S.items[i].key = 1.0f / (float)NA; S.items[i].idx = d.uniform_order[i]; }
     }
     __syncthreads();
+    if (pi && lane == 0) stdorder::sort_desc(S.items, NA);     // std::sort, MCTSGameActor.h:295-300
+    __syncthreads();
+    // checkMove filter (:305-331): the legal items keep their sorted order.  Lanes test 64 items at a
+    // time; an item's slot is the number of legal items before it (ballot + popcount).
+    int kept = 0;
+    for (int c = 0; c < NA; c += 64) {
+      const int i = c + lane;
+      const bool in = i < NA;
+      const int a = in ? (int)S.items[in ? i : 0].idx : 0;
+      uint64_t word = 0;
+#pragma unroll
+      for (int q = 0; q < (NA + 63) / 64; ++q) word = (a >> 6) == q ? mk[q] : word;
+      const bool legal = in && ((word >> (a & 63)) & 1);
+      const unsigned long long b = __ballot(legal);
+      const int pos = kept + __popcll(b & ((1ull << lane) - 1ull));
+      if (legal && pos < MAXLEGAL) { S.keys[pos] = (uint16_t)a; S.pri[pos] = S.items[i].key; }
+      kept += __popcll(b);
+    }
+    __syncthreads();
     if (lane == 0) {
-      if (pi) stdorder::sort_desc(S.items, NA);              // std::sort, MCTSGameActor.h:295-300
-      int mm = 0; bool over = false;
-      for (int i = 0; i < NA; ++i) {                          // checkMove filter :305-331
-        const int a = S.items[i].idx;
-        if ((mk[a >> 6] >> (a & 63)) & 1) {
-          if (mm < MAXLEGAL) { S.keys[mm] = (uint16_t)a; S.pri[mm] = S.items[i].key; ++mm; } else over = true;
-        }
-      }
+      const bool over = kept > MAXLEGAL;
+      const int mm = over ? MAXLEGAL : kept;
       float tot = 1e-10f;                                     // normalize :240-251
       for (int k = 0; k < mm; ++k) tot += S.pri[k];
       for (int k = 0; k < mm; ++k) S.pri[k] /= tot;
@@ -209,6 +235,7 @@ __device__ inline void expand_edges(const TreeDev& d, TV& tv, int leaf, bool ter
 // backup of one batch (tree_search.h:291-305 + updateEdgeStats tree_search_node.h:267-292):
 // per DISTINCT leaf, along the first trajectory that reached it; duplicates only raise `count`.
 __device__ inline void backup_batch(const TreeDev& d, TV& tv, const Opt& o, int t, const int* leafs) {
+  const int lane = threadIdx.x & 63;
   for (int j = 0; j < o.B; ++j) {
     const int leaf = leafs[j];
     bool first = true; int count = 0;
@@ -218,7 +245,9 @@ __device__ inline void backup_batch(const TreeDev& d, TV& tv, const Opt& o, int 
     const int len = d.traj_len[(size_t)t * o.B + j];
     const uint16_t* tn = d.traj_node + ((size_t)t * o.B + j) * MAXD;
     const uint16_t* te = d.traj_edge + ((size_t)t * o.B + j) * MAXD;
-    for (int i = 0; i < len; ++i) {
+    // the steps of one trajectory touch distinct nodes and edges: one lane per step; trajectories
+    // (which share the nodes near the root) stay in order
+    for (int i = lane; i < len; i += 64) {
       const int node = tn[i];
       const int e = (int)tv.ebase[node] + te[i];
       tv.visits[node] = tv.visits[node] + 1;
@@ -226,8 +255,9 @@ __device__ inline void backup_batch(const TreeDev& d, TV& tv, const Opt& o, int 
       tv.ev[e] = tv.ev[e] + 1;
       tv.el[e] = tv.el[e] - (float)(o.vl * count);
     }
+    __threadfence_block();
+    __syncthreads();
   }
-  __threadfence_block();
 }
 
 // ---- kernels (grid = n_trees blocks of one wave) ------------------------------------------------
