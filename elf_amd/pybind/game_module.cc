@@ -21,6 +21,7 @@
 #include <array>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <random>
 
 #include "../../include/elfhip.h"
@@ -113,6 +114,8 @@ struct GameRecord {  // what GuardedRecords keeps per finished game (game/Record
   int game_idx = 0;
   long long seq = 0;
   float reward = 0;
+  int num_move = 0;            // getPly() - 1 at the end (GameStateExt::dumpRecord, game/GameStateExt.h:47-76)
+  long long timestamp = 0;
   std::vector<int16_t> moves;
   std::vector<float> values;
   std::vector<std::vector<uint8_t>> policies;
@@ -324,6 +327,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
     for (auto& r : records_) {
       py::dict d;
       d["game_idx"] = r.game_idx; d["seq"] = r.seq; d["reward"] = r.reward; d["moves"] = r.moves; d["values"] = r.values;
+      d["num_move"] = r.num_move; d["timestamp"] = r.timestamp;
       py::list pl;
       for (auto& p : r.policies) pl.append(py::bytes((const char*)p.data(), p.size()));
       d["policies"] = pl;
@@ -331,6 +335,50 @@ class SelfPlayEngine : public elfhip_py::Engine {
     }
     records_.clear();
     return l;
+  }
+  // GameRecord::dumpBatchJsonString (game/Record.h:179-189): the JSON a DistriClient sends to the
+  // trainer and that --list_files reloads.  Same object layout and key names: request{vers{black_ver,
+  // white_ver,mcts_opt{...}},client_ctrl{...}}, result{num_move,reward,using_models,content,policies,
+  // values}, timestamp, thread_id, seq, pri, offline; moves as "(;[12];[98])" (sgf/sgf.h:34-41).
+  py::dict request_dict() const {
+    const TSOptions& t = co_.mcts_options;
+    py::dict alg, mo, vers, cc, req;
+    alg["use_prior"] = t.alg_opt.use_prior; alg["c_puct"] = t.alg_opt.c_puct;
+    alg["unexplored_q_zero"] = t.alg_opt.unexplored_q_zero; alg["root_unexplored_q_zero"] = t.alg_opt.root_unexplored_q_zero;
+    mo["max_num_moves"] = t.max_num_moves; mo["num_threads"] = t.num_threads;
+    mo["num_rollouts_per_thread"] = t.num_rollouts_per_thread; mo["num_rollouts_per_batch"] = t.num_rollouts_per_batch;
+    mo["verbose"] = t.verbose; mo["verbose_time"] = t.verbose_time; mo["seed"] = t.seed; mo["persistent_tree"] = t.persistent_tree;
+    mo["pick_method"] = t.pick_method; mo["log_prefix"] = t.log_prefix; mo["root_epsilon"] = t.root_epsilon;
+    mo["root_alpha"] = t.root_alpha; mo["virtual_loss"] = t.virtual_loss; mo["alg_opt"] = alg;
+    vers["black_ver"] = client_.black_ver; vers["white_ver"] = client_.white_ver; vers["mcts_opt"] = mo;
+    cc["client_type"] = client_.white_ver >= 0 ? 2 : 1;  // CLIENT_EVAL_THEN_SELFPLAY : CLIENT_SELFPLAY_ONLY (common/record.h:30-34)
+    cc["num_game_thread_used"] = -1; cc["player_swap"] = false; cc["async"] = false;
+    req["vers"] = vers; req["client_ctrl"] = cc;
+    return req;
+  }
+  std::string dump_records_json(bool clear) {
+    py::list out;
+    const py::dict req = request_dict();
+    for (auto& r : records_) {
+      py::dict res, rec;
+      std::string content = "(";
+      for (int16_t m : r.moves) content += ";[" + std::to_string((int)m) + "]";
+      content += ")";
+      py::list models;
+      if (client_.black_ver >= 0) models.append(client_.black_ver);
+      if (client_.white_ver >= 0) models.append(client_.white_ver);
+      py::list pols;
+      for (auto& p : r.policies) { py::list row; for (uint8_t c : p) row.append((int)c); pols.append(row); }
+      res["num_move"] = r.num_move; res["reward"] = r.reward; res["using_models"] = models; res["content"] = content;
+      if (!r.policies.empty()) res["policies"] = pols;  // nlohmann creates the key on the first push_back only
+      res["values"] = r.values;
+      rec["request"] = req; rec["result"] = res; rec["timestamp"] = r.timestamp; rec["thread_id"] = r.game_idx;
+      rec["seq"] = r.seq; rec["pri"] = 0.0; rec["offline"] = false;
+      out.append(rec);
+    }
+    if (clear) records_.clear();
+    py::object dumps = py::module_::import("json").attr("dumps");
+    return py::cast<std::string>(dumps(out, py::arg("sort_keys") = true, py::arg("separators") = py::make_tuple(",", ":")));
   }
   py::dict search_stats() {
     need_running();
@@ -430,6 +478,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
         if (h_ply_[i] >= gi_.max_ply) w.both_lost++; else if (r > 0) w.black_wins++; else w.white_wins++;
         w.sum_reward += r; w.total_games++;
         cur_[i].game_idx = i; cur_[i].seq = seq_[i]++; cur_[i].reward = r;
+        cur_[i].num_move = h_ply_[i] - 1; cur_[i].timestamp = (long long)std::time(nullptr);
         records_.push_back(std::move(cur_[i]));
         cur_[i] = GameRecord();
         if (label("game_end")) {
@@ -492,6 +541,7 @@ class GameContext {  // elfgames/<game>/train/GameContext.h:46-160
   DistriClient* getClient() { return eng_->client(); }
   py::object getServer() { return py::none(); }  // training side: out of scope
   py::list takeRecords() { return eng_->take_records(); }
+  std::string dumpRecordsJson(bool clear) { return eng_->dump_records_json(clear); }
   py::dict searchStats() { return eng_->search_stats(); }
 
  private:
@@ -517,6 +567,7 @@ PYBIND11_MODULE(ELFGAME_MODULE, m) {
       // no reference counterpart: finished-game records as arrays (the reference ships them as JSON
       // over ZMQ, DistriClient.h:104-122) and the search counters of elfhip_mcts_stats
       .def("takeRecords", &GameContext::takeRecords)
+      .def("dumpRecordsJson", &GameContext::dumpRecordsJson, py::arg("clear") = true)
       .def("searchStats", &GameContext::searchStats);
 
   py::class_<DistriClient>(m, "DistriClient", py::module_local())

@@ -58,7 +58,23 @@ def test_facade_selfplay_matches_oracle(batchsize):
             break
     assert counts["actor_white"] == 0            # one model: every leaf goes to actor_black (_ai1)
     assert ends == sorted(ends) and ends[-1] >= 2 * n
+    # the reference's record JSON (GameRecord::dumpBatchJsonString, game/Record.h:87-189; sgf/sgf.h:34-41)
+    import json
+    js = json.loads(GC.dumpRecordsJson(clear=False))
     recs = GC.takeRecords()
+    assert len(js) == len(recs)
+    for j, r in zip(js, recs):
+        assert set(j) == {"request", "result", "timestamp", "thread_id", "seq", "pri", "offline"}
+        assert set(j["request"]) == {"vers", "client_ctrl"} and set(j["request"]["vers"]) == {"black_ver", "white_ver", "mcts_opt"}
+        assert set(j["request"]["client_ctrl"]) == {"client_type", "num_game_thread_used", "player_swap", "async"}
+        mo = j["request"]["vers"]["mcts_opt"]
+        assert mo["num_rollouts_per_thread"] == 24 and mo["num_rollouts_per_batch"] == 4 and mo["alg_opt"]["c_puct"] == 1.5
+        assert set(j["result"]) == {"num_move", "reward", "using_models", "content", "policies", "values"}
+        assert j["result"]["content"] == "(" + "".join(";[%d]" % m for m in r["moves"]) + ")"
+        assert j["result"]["num_move"] == len(r["moves"]) and j["result"]["reward"] == r["reward"]
+        assert j["result"]["values"] == [float(v) for v in r["values"]]
+        assert [bytes(p) for p in j["result"]["policies"]] == list(r["policies"])
+        assert j["thread_id"] == r["game_idx"] and j["seq"] == r["seq"] and j["offline"] is False
     st = GC.searchStats()
     assert st["rollouts"] > 0 and st["evals"] > 0
     wr = GC.getClient().getGameStats().getWinRateStats()
