@@ -7,11 +7,12 @@
 // incrementally, which makes the whole-board legal mask pure bit arithmetic:
 //     T = empty | (own & ~AT) | (opp & AT)          legal = empty & neighbours(T) & ~ko
 // (a point is playable iff it touches an empty point, an own group that keeps a liberty, or an
-// opponent group in atari).  Groups are found by row-sweep flood fills whose exit is a wave-wide
-// ballot (__any), so all 64 boards of a wavefront iterate together.  Boards are struct-of-arrays
+// opponent group in atari).  Groups are grown by alternating row sweeps whose exit is a wave-wide
+// ballot (__any), so all 64 boards of a wavefront iterate together; after a move a group is grown
+// only until its liberty status is decided (go_dev.h: go_group_status).  Boards are struct-of-arrays
 // in HBM (u32 word w of board b at [w*n + b]) so loads/stores are coalesced 4 B/lane.
-// Positional superko uses a per-board open-addressing table of 1024 x {hash, game generation}
-// in HBM (16 KB/board, sized for 288 GB parts) instead of scanning the move history.
+// Positional superko uses a per-board open-addressing table of 512 buckets x 4 {hash, game
+// generation} in HBM (32 KB/board, sized for 288 GB parts) instead of scanning the move history.
 #include "common.h"
 #include "go_dev.h"
 
