@@ -37,7 +37,23 @@ def build(force=False, verbose=False):
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
     build_pybind(force=force or bool(procs), verbose=verbose)
+    build_cpp_tests(force=force or bool(procs), verbose=verbose)
     return LIB
+
+
+def build_cpp_tests(force=False, verbose=False):
+    """tests/cpp/*.cc: host C++ programs over include/elfhip_tree_search.hpp (run by the GPU tests)."""
+    root = os.path.join(HERE, "..")
+    hdrs = glob.glob(os.path.join(root, "include", "*"))
+    for src in sorted(glob.glob(os.path.join(root, "tests", "cpp", "*.cc"))):
+        out = src[:-3] + ".bin"
+        if force or _newer(src, out) or any(_newer(h, out) for h in hdrs):
+            cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                   "-I" + os.path.join(root, "include"), src, "-o", out, "-L" + HERE, "-lelfhip", "-L/opt/rocm/lib", "-lamdhip64",
+                   "-Wl,-rpath,$ORIGIN/../../elf_amd", "-Wl,-rpath,/opt/rocm/lib"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
 
 
 # Python-visible facade modules with the reference's module names (host C++ only, g++):

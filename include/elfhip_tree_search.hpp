@@ -1,0 +1,202 @@
+// elfhip_tree_search.hpp - C++ face of the batched tree search for code written against the
+// reference's elf::ai::tree_search templates (src_cpp/elf/ai/tree_search/tree_search.h:405-622,
+// tree_search_base.h:137-367, tree_search_options.h:24-29,91-110, mcts.h:48-203).
+//
+// The reference instantiates one TreeSearchT<State, Action, Actor> per game thread and calls
+//   run(state) -> MCTSResultT<Action>,  treeAdvance(action),  clear()
+// with the Actor evaluating leaves through the batch collector.  Here ONE object holds n trees in
+// HBM (one wavefront per tree) and the same three calls act on all of them; the "Actor" is a
+// callable that receives the device batch of leaf planes and fills the device batch of (pi, V):
+//   void evaluate(const float* d_s /*[n*B][planes][size][size]*/, const uint8_t* d_need /*[n*B]*/,
+//                 float* d_pi /*[n*B][num_action]*/, float* d_v /*[n*B]*/, int rows);
+// Field names of TSOptions / SearchAlgoOptions / EdgeInfo / MCTSResultT are the reference's, so the
+// call sites read the same.  Header only; needs libelfhip.so and the HIP runtime (for the result
+// buffers).  num_threads is carried but searched serially (num_threads x num_rollouts_per_thread).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "elfhip.h"
+
+namespace elfhip {
+namespace tree_search {
+
+struct SearchAlgoOptions {
+  bool use_prior = true;
+  float c_puct = 5;
+  bool unexplored_q_zero = false;
+  bool root_unexplored_q_zero = false;
+};
+
+struct TSOptions {
+  int max_num_moves = 0;
+  int num_threads = 16;
+  int num_rollouts_per_thread = 100;
+  int num_rollouts_per_batch = 8;
+  bool verbose = true;
+  bool verbose_time = false;
+  bool persistent_tree = true;
+  float root_epsilon = 0.0;
+  float root_alpha = 0.0;
+  std::string pick_method = "most_visited";
+  int virtual_loss = 0;
+  SearchAlgoOptions alg_opt;
+  std::string log_prefix = "";
+  int seed = 0;
+};
+
+struct EdgeInfo {  // tree_search_base.h:137-159 (child_node is internal to the device arena)
+  float prior_probability = 0;
+  float reward = 0;
+  int num_visits = 0;
+  float getQSA() const { return reward / num_visits; }
+};
+
+template <typename Action>
+struct MCTSResultT {  // tree_search_base.h:284-367
+  enum RankCriterion { MOST_VISITED = 0, PRIOR = 1, UNIFORM_RANDOM };
+  Action best_action = Action(-1);
+  float root_value = 0.0f;
+  float max_score = std::numeric_limits<float>::lowest();
+  EdgeInfo best_edge_info;
+  std::vector<std::pair<Action, EdgeInfo>> action_edge_pairs;  // in the reference's edge iteration order
+  int total_visits = 0;
+  RankCriterion action_rank_method = MOST_VISITED;
+};
+
+template <typename Action = int16_t>
+class TreeSearchBatchT {
+ public:
+  using MCTSResult = MCTSResultT<Action>;
+
+  TreeSearchBatchT(int game, int n_trees, const TSOptions& o, int device = 0) : n_(n_trees), device_(device), opt_(o) {
+    check(elfhip_game_get_info(game, &gi_), "game_get_info");
+    if (o.pick_method != "most_visited" && o.pick_method != "strongest_prior")
+      throw std::range_error("MCTS Pick method unknown! " + o.pick_method);  // tree_search.h:615
+    rank_ = o.pick_method == "most_visited" ? MCTSResult::MOST_VISITED : MCTSResult::PRIOR;
+    B_ = o.num_rollouts_per_batch;
+    R_ = o.num_rollouts_per_thread * (o.num_threads > 0 ? o.num_threads : 1);
+    elfhip_ts_options t{R_, B_, o.virtual_loss, o.alg_opt.use_prior ? 1 : 0, o.alg_opt.c_puct, o.alg_opt.unexplored_q_zero ? 1 : 0,
+                        o.alg_opt.root_unexplored_q_zero ? 1 : 0, o.persistent_tree ? 1 : 0, rank_ == MCTSResult::PRIOR ? 1 : 0, 0, 0};
+    check(elfhip_mcts_create(game, n_trees, &t, device, &h_), "mcts_create");
+    hip(hipSetDevice(device), "hipSetDevice");
+    const size_t slots = (size_t)n_ * B_, plane = (size_t)gi_.num_planes * gi_.board_size * gi_.board_size;
+    alloc(&d_s_, slots * plane * 4); alloc(&d_need_, slots); alloc(&d_pi_, slots * gi_.num_actions * 4); alloc(&d_v_, slots * 4);
+    alloc(&d_best_, (size_t)n_ * 2); alloc(&d_tot_, (size_t)n_ * 4); alloc(&d_rootv_, (size_t)n_ * 4); alloc(&d_ne_, (size_t)n_ * 4);
+    cap_ = gi_.num_actions;
+    alloc(&d_ea_, (size_t)n_ * cap_ * 2); alloc(&d_ev_, (size_t)n_ * cap_ * 4); alloc(&d_er_, (size_t)n_ * cap_ * 4);
+    alloc(&d_ep_, (size_t)n_ * cap_ * 4); alloc(&d_act_, (size_t)n_ * 2);
+    hip(hipMemset(d_pi_, 0, slots * gi_.num_actions * 4), "memset");
+    hip(hipMemset(d_v_, 0, slots * 4), "memset");
+  }
+  ~TreeSearchBatchT() {
+    if (h_) elfhip_mcts_destroy(h_);
+    for (void* p : allocs_) (void)hipFree(p);
+  }
+  TreeSearchBatchT(const TreeSearchBatchT&) = delete;
+  TreeSearchBatchT& operator=(const TreeSearchBatchT&) = delete;
+
+  // MCTSActorParams::seed of every tree's actor (root noise generator)
+  void setSeeds(const std::vector<uint32_t>& seeds) {
+    if ((int)seeds.size() != n_) throw std::invalid_argument("setSeeds: one seed per tree");
+    check(elfhip_mcts_seed_rng(h_, seeds.data()), "mcts_seed_rng");
+  }
+
+  // TreeSearchT::run(root_state) for every tree: roots = the n boards of `b`
+  template <class Evaluate>
+  std::vector<MCTSResult> run(elfhip_boards* b, Evaluate&& evaluate) {
+    prologue(b);
+    for (int r = 0; r < R_; r += B_) {
+      check(elfhip_mcts_select(h_, nullptr, (float*)d_s_, (uint8_t*)d_need_), "mcts_select");
+      evaluate((const float*)d_s_, (const uint8_t*)d_need_, (float*)d_pi_, (float*)d_v_, n_ * B_);
+      check(elfhip_mcts_backup(h_, (const float*)d_pi_, (const float*)d_v_), "mcts_backup");
+    }
+    return results();
+  }
+  // the same with the built-in uniform evaluator (pi = 1/num_action, V = 0): all rollouts in one launch
+  std::vector<MCTSResult> runUniform(elfhip_boards* b) {
+    prologue(b);
+    check(elfhip_mcts_run_uniform(h_), "mcts_run_uniform");
+    return results();
+  }
+  void treeAdvance(const std::vector<Action>& actions) {  // tree_search_node.h:458-474
+    if ((int)actions.size() != n_) throw std::invalid_argument("treeAdvance: one action per tree");
+    std::vector<int16_t> a(actions.begin(), actions.end());
+    hip(hipMemcpy(d_act_, a.data(), (size_t)n_ * 2, hipMemcpyHostToDevice), "copy actions");
+    check(elfhip_mcts_advance(h_, (const int16_t*)d_act_), "mcts_advance");
+  }
+  void clear() { check(elfhip_mcts_clear(h_, nullptr), "mcts_clear"); }  // MCTSAI_T::resetTree
+  elfhip_mcts* handle() { return h_; }
+  int num_trees() const { return n_; }
+  const elfhip_game_info& game_info() const { return gi_; }
+
+ private:
+  static void check(int rc, const char* what) {
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + elfhip_last_error());
+  }
+  static void hip(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+  }
+  void alloc(void** p, size_t bytes) { hip(hipMalloc(p, bytes ? bytes : 4), "hipMalloc"); allocs_.push_back(*p); }
+  void prologue(elfhip_boards* b) {
+    std::vector<uint8_t> ok(n_);
+    void* d_ok = d_need_;  // reuse: n <= n*B bytes
+    check(elfhip_mcts_set_roots(h_, b, (uint8_t*)d_ok), "mcts_set_roots");
+    hip(hipMemcpy(ok.data(), d_ok, (size_t)n_, hipMemcpyDeviceToHost), "copy ok");
+    for (int i = 0; i < n_; ++i)
+      if (!ok[i]) throw std::range_error("TreeSearch::Root state is not the same as the input state");  // tree_search.h:580-584
+    if (opt_.root_epsilon > 0.0f) check(elfhip_mcts_root_noise(h_, opt_.root_epsilon, opt_.root_alpha), "mcts_root_noise");
+  }
+  std::vector<MCTSResult> results() {  // chooseAction / MCTSResultT::addActions
+    check(elfhip_mcts_result(h_, (int16_t*)d_best_, (int32_t*)d_tot_, nullptr, (float*)d_rootv_, (int32_t*)d_ne_, (int16_t*)d_ea_,
+                             (int32_t*)d_ev_, (float*)d_er_, (float*)d_ep_, cap_, nullptr), "mcts_result");
+    std::vector<int16_t> best(n_), ea((size_t)n_ * cap_);
+    std::vector<int32_t> tot(n_), ne(n_), ev((size_t)n_ * cap_);
+    std::vector<float> rv(n_), er((size_t)n_ * cap_), ep((size_t)n_ * cap_);
+    hip(hipMemcpy(best.data(), d_best_, (size_t)n_ * 2, hipMemcpyDeviceToHost), "copy");
+    hip(hipMemcpy(tot.data(), d_tot_, (size_t)n_ * 4, hipMemcpyDeviceToHost), "copy");
+    hip(hipMemcpy(rv.data(), d_rootv_, (size_t)n_ * 4, hipMemcpyDeviceToHost), "copy");
+    hip(hipMemcpy(ne.data(), d_ne_, (size_t)n_ * 4, hipMemcpyDeviceToHost), "copy");
+    hip(hipMemcpy(ea.data(), d_ea_, ea.size() * 2, hipMemcpyDeviceToHost), "copy");
+    hip(hipMemcpy(ev.data(), d_ev_, ev.size() * 4, hipMemcpyDeviceToHost), "copy");
+    hip(hipMemcpy(er.data(), d_er_, er.size() * 4, hipMemcpyDeviceToHost), "copy");
+    hip(hipMemcpy(ep.data(), d_ep_, ep.size() * 4, hipMemcpyDeviceToHost), "copy");
+    std::vector<MCTSResult> out(n_);
+    for (int i = 0; i < n_; ++i) {
+      MCTSResult& r = out[i];
+      r.action_rank_method = rank_;
+      r.root_value = rv[i];
+      r.total_visits = tot[i];
+      for (int j = 0; j < ne[i] && j < cap_; ++j) {
+        EdgeInfo e;
+        e.prior_probability = ep[(size_t)i * cap_ + j]; e.reward = er[(size_t)i * cap_ + j]; e.num_visits = ev[(size_t)i * cap_ + j];
+        const Action a = (Action)ea[(size_t)i * cap_ + j];
+        r.action_edge_pairs.emplace_back(a, e);
+        const float score = rank_ == MCTSResult::MOST_VISITED ? (float)e.num_visits : e.prior_probability;
+        if (score > r.max_score) { r.max_score = score; r.best_action = a; r.best_edge_info = e; }
+      }
+      if (ne[i] > 0 && r.best_action != (Action)best[i]) throw std::logic_error("result: host and device ranking disagree");
+    }
+    return out;
+  }
+
+  int n_, device_, B_ = 1, R_ = 1, cap_ = 0;
+  TSOptions opt_;
+  typename MCTSResult::RankCriterion rank_;
+  elfhip_game_info gi_{};
+  elfhip_mcts* h_ = nullptr;
+  std::vector<void*> allocs_;
+  void *d_s_ = nullptr, *d_need_ = nullptr, *d_pi_ = nullptr, *d_v_ = nullptr, *d_best_ = nullptr, *d_tot_ = nullptr,
+       *d_rootv_ = nullptr, *d_ne_ = nullptr, *d_ea_ = nullptr, *d_ev_ = nullptr, *d_er_ = nullptr, *d_ep_ = nullptr, *d_act_ = nullptr;
+};
+
+using TreeSearchBatch = TreeSearchBatchT<int16_t>;
+
+}  // namespace tree_search
+}  // namespace elfhip
