@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(64) go_mask_kernel(GoDev d, uint64_t* __restri
 
 __global__ void __launch_bounds__(64) go_step_kernel(GoDev d, const uint64_t* __restrict__ gz,
                                                      const int16_t* __restrict__ actions, uint8_t* __restrict__ ok) {
-  __shared__ uint64_t z[2 * GO_POINTS];
+  __shared__ uint64_t z[GO_ZWORDS];
   go_load_zobrist(z, gz);
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = b < d.n;
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(64) go_step_kernel(GoDev d, const uint64_t* __
 __global__ void __launch_bounds__(64)
 go_playout_kernel(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t seed, uint64_t first_id,
                   uint64_t step_base, unsigned long long* __restrict__ moves_out) {
-  __shared__ uint64_t z[2 * GO_POINTS];
+  __shared__ uint64_t z[GO_ZWORDS];
   go_load_zobrist(z, gz);
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = b < d.n;

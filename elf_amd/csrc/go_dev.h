@@ -29,6 +29,11 @@ constexpr int TAB_SLOTS = 2048;                  // superko set entries per boar
 constexpr int TAB_BUCKETS = TAB_SLOTS / 4;        // buckets of 4 x {hash, generation} = one 64-byte line
 constexpr int GO_WORDS = 22;
 constexpr int NROWW = 57;  // B[19], W[19], AT[19]
+// LDS Zobrist block: [0, 722) the per-point keys z[colour*361 + point]; then the row-chunk table
+// zc[colour][row][chunk 0..4][16]: XOR of the keys of the stones in a 4-column nibble of a row, so the
+// keys of a whole captured row come out of 5 lookups instead of one dependent lookup per stone
+constexpr int GO_ZC_BASE = 2 * GO_POINTS, GO_ZC_ROW = 5 * 16;
+constexpr int GO_ZWORDS = GO_ZC_BASE + 2 * GN * GO_ZC_ROW;
 
 #define ROWS(i) _Pragma("unroll") for (int i = 0; i < GN; ++i)
 #define ROWS_REV(i) _Pragma("unroll") for (int i = GN - 1; i >= 0; --i)
@@ -231,9 +236,10 @@ __device__ inline void go_place(GoS& s, bool act, uint32_t r, uint32_t bit, cons
       s.AT[i] &= ~F[i];
       ncap += __popc(F[i]);
       if (F[i]) cap_pt = i * 19 + (__ffs(F[i]) - 1);
-      uint32_t m = F[i];
-      while (__any(m != 0)) {
-        if (m) { int c = __ffs(m) - 1; m &= m - 1; s.hash ^= z[(s.tm ^ 1) * GO_POINTS + i * 19 + c]; }
+      if (__any(F[i] != 0)) {
+        const uint64_t* t = z + GO_ZC_BASE + ((s.tm ^ 1) * GN + i) * GO_ZC_ROW;
+        const uint32_t f = F[i];
+        s.hash ^= t[f & 15] ^ t[16 + ((f >> 4) & 15)] ^ t[32 + ((f >> 8) & 15)] ^ t[48 + ((f >> 12) & 15)] ^ t[64 + (f >> 16)];
       }
     }
     // own groups in atari next to the captured stones gain a liberty: they leave AT
@@ -402,6 +408,16 @@ __device__ inline void go_store(const GoDev& d, int b, const GoS& s) {
 
 __device__ inline void go_load_zobrist(uint64_t* z, const uint64_t* gz) {
   for (int i = threadIdx.x; i < 2 * GO_POINTS; i += blockDim.x) z[i] = gz[i];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * GN * GO_ZC_ROW; e += blockDim.x) {
+    const int v = e & 15, chunk = (e >> 4) % 5, cr = e / GO_ZC_ROW;  // cr = colour * 19 + row
+    uint64_t x = 0;
+    for (int b = 0; b < 4; ++b) {
+      const int col = chunk * 4 + b;
+      if (((v >> b) & 1) && col < GN) x ^= z[(cr / GN) * GO_POINTS + (cr % GN) * GN + col];
+    }
+    z[GO_ZC_BASE + e] = x;
+  }
   __syncthreads();
 }
 

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(64) go_tree_select_kernel(TreeDev d, Opt o) {
 __global__ void __launch_bounds__(64)
 go_tree_expand_kernel(TreeDev d, Opt o, GoDev g, const uint64_t* __restrict__ gz, GoX x, uint64_t* __restrict__ leaf_states,
                       uint8_t* __restrict__ need_eval) {
-  __shared__ uint64_t z[2 * GO_POINTS];
+  __shared__ uint64_t z[GO_ZWORDS];
   go_load_zobrist(z, gz);
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   const int nslots = d.n_trees * o.B;

@@ -240,6 +240,18 @@ class SelfPlayEngine : public elfhip_py::Engine {
       if (!out_.empty()) { SharedMem* m = out_.front(); out_.pop_front(); return m; }
       switch (phase_) {
         case BEGIN:
+          if (restart_pending_) {  // OnReceive -> restart() -> UPDATE_MODEL -> one "game_start" batch
+            restart_pending_ = false;  // (ClientGameSelfPlay.cc:198-247, DispatcherCallback.h:61-111)
+            restart_all();
+            if (label("game_start")) {
+              SharedMem* m = pick_smem("game_start");
+              if (AnyP* k = key(m, "black_ver")) *(int64_t*)k->row(0) = client_.black_ver;
+              if (AnyP* k = key(m, "white_ver")) *(int64_t*)k->row(0) = client_.white_ver;
+              m->effective_batchsize = 1;
+              out_.push_back(m);
+              break;
+            }
+          }
           ck(elfhip_mcts_set_roots(mcts_, boards_, nullptr), "mcts_set_roots");
           if (co_.mcts_options.root_epsilon > 0.0f)  // TreeSearchT::run, tree_search.h:502-506
             ck(elfhip_mcts_root_noise(mcts_, co_.mcts_options.root_epsilon, co_.mcts_options.root_alpha), "mcts_root_noise");
@@ -301,6 +313,20 @@ class SelfPlayEngine : public elfhip_py::Engine {
   }
 
   void stop() override { running_ = false; release(); }
+
+  // DistriClient::setRequest: a request whose versions differ from the current ones restarts every game
+  // at the next move boundary (the reference's games poll their mailbox between moves)
+  void on_request(long long black, long long white) {
+    const bool same = black == client_.black_ver && white == client_.white_ver;
+    client_.black_ver = black; client_.white_ver = white;
+    if (running_ && !same) restart_pending_ = true;
+  }
+  void restart_all() {
+    ck(elfhip_mcts_clear(mcts_, nullptr), "mcts_clear");
+    ck(elfhip_boards_reset(boards_), "boards_reset");
+    for (auto& r : cur_) r = GameRecord();
+    refresh_states();
+  }
 
   // ---- accessors used by the Python-visible helper objects ----
   DistriClient* client() { return &client_; }
@@ -522,12 +548,12 @@ class SelfPlayEngine : public elfhip_py::Engine {
   size_t cursor_ = 0;
   uint64_t move_counter_ = 0;
   SharedMem* serving_ = nullptr;
-  bool running_ = false;
+  bool running_ = false, restart_pending_ = false;
   DistriClient client_;
   std::vector<ClientGameSelfPlay> games_;
 };
 
-void DistriClient::setRequest(long long black, long long white, int) { black_ver = black; white_ver = white; }
+void DistriClient::setRequest(long long black, long long white, int) { eng->on_request(black, white); }
 int ClientGameSelfPlay::getCurrentPlayer() const { return eng->player_of(idx); }
 std::vector<int> ClientGameSelfPlay::getValidMoves() const { return eng->valid_moves_of(idx); }
 std::vector<uint64_t> ClientGameSelfPlay::getStateWords() const { return eng->state_of(idx); }

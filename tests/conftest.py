@@ -15,3 +15,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionstart(session):
+    """torch ships its own HIP runtime (torch/lib/libamdhip64.so) next to the system one that libelfhip.so and
+    the facade modules link; torch only finds the GPU when ITS runtime initialises first, so touch it before
+    any test can load the facade (which never imports torch)."""
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:
+        pass

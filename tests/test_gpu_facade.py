@@ -194,3 +194,43 @@ def test_facade_other_games_match_oracle_search(game):
         assert list(r["moves"]) == moves
         assert r["reward"] == g.evaluate()
     w.stop()
+
+
+def test_facade_set_request_restarts_games_and_sends_game_start():
+    """DistriClient.setRequest with new versions: every game restarts at the next move boundary and ONE
+    game_start batch carries (black_ver, white_ver) to Python (ClientGameSelfPlay.cc:198-247,
+    DispatcherCallback.h:61-111); the record JSON then names the new model."""
+    import json
+    import _elfgames_american_checkers as ac
+    co = ac.ContextOptions()
+    co.num_games, co.batchsize = 4, 32
+    m = co.mcts_options
+    m.num_threads, m.num_rollouts_per_thread, m.num_rollouts_per_batch, m.virtual_loss, m.alg_opt.c_puct = 1, 8, 4, 1, 1.5
+    go = ac.GameOptions()
+    go.mode, go.policy_distri_cutoff = "selfplay", 0
+    GC = ac.GameContext(co, go)
+    desc = dict(game_end=dict(batchsize=1), game_start=dict(batchsize=1, input=["white_ver", "black_ver"], reply=None),
+                actor_black=dict(input=["s"], reply=["pi", "V", "a", "rv"], batchsize=32))
+    w = _gcwrapper.Wrapper(GC, 32, desc, num_recv=2)
+    starts, ends = [], []
+    w.reg_callback("actor_black", _uniform)
+    w.reg_callback("game_start", lambda batch, bs: starts.append((int(batch["black_ver"][0]), int(batch["white_ver"][0]))))
+    w.reg_callback("game_end", lambda batch, bs: ends.append(1))
+    w.start()
+    for _ in range(30):
+        w.run()
+    assert not starts
+    mid = GC.getGame(0).getStateWords()
+    assert (mid[4] >> 8) & 0xFFFF > 1                      # games are under way
+    GC.getClient().setRequest(5, -1, 1)
+    names = [w.run()[0] for _ in range(8)]
+    assert starts == [(5, -1)] and names.count("game_start") == 1
+    GC.getClient().setRequest(5, -1, 1)                    # same versions: UPDATE_REQUEST_ONLY, no restart
+    for _ in range(200000):
+        w.run()
+        if len(ends) >= 4:
+            break
+    assert starts == [(5, -1)]
+    js = json.loads(GC.dumpRecordsJson())
+    assert js and all(j["request"]["vers"]["black_ver"] == 5 and j["result"]["using_models"] == [5] and j["seq"] == 0 for j in js)
+    w.stop()
