@@ -199,9 +199,14 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave & 1, wp = wave >> 1;
   const int r16 = lane & 15, q = lane >> 4;
-  const int board0 = blockIdx.x * NBW;
-  const long xrow0 = (long)board0 * PP;
-  const int rows_left = (int)min((long)XROWS, (long)B * PP - xrow0);   // padded rows that exist from xrow0 on
+  // Persistent: this workgroup owns board groups blockIdx.x, blockIdx.x + gridDim.x, ... and runs ONE
+  // continuous pipeline over all of them: the weight ring and the activation double buffer are indexed
+  // by a stage / chunk counter that keeps counting across boards, so the first weight slices and the
+  // first activation chunk of the next board group are already in LDS (or in flight) while the
+  // epilogue of the current one stores its outputs.
+  const int ngroups = (B + NBW - 1) / NBW;
+  const int nmine = ((int)blockIdx.x < ngroups) ? (ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  if (nmine == 0) return;
 
   // per position tile of this lane: padded row, and the byte offset of its (dy,dx) = (-1,-1) neighbour
   int pb[NTW];
@@ -212,33 +217,32 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
     const int bl = p / HW, rem = p % HW, y = rem / H, xw = rem % H;
     pb[nt] = (bl * PP + (y + 1) * PW + xw + 1 - (PW + 1)) * 80 + q * 16;
   }
-  // DMA source offsets (bytes, relative to the workgroup's first padded row / the weight slice)
-  uint32_t xoff[NXW], aoff[NAW];
-#pragma unroll
-  for (int i = 0; i < NXW; ++i) {
-    const int slot = (wave + 8 * i) * 64 + lane;
-    int row = slot / 5, ch = slot - row * 5;
-    ch = ch == 4 ? 0 : ch;
-    row = row < rows_left ? row : rows_left - 1;
-    xoff[i] = (uint32_t)(row * CIN + ch * 8) * 2u;
-  }
+  // DMA source offsets (bytes, relative to the group's first padded row / the weight slice)
+  uint32_t aoff[NAW];
 #pragma unroll
   for (int i = 0; i < NAW; ++i) aoff[i] = (uint32_t)(((wave + 8 * i) * 16 + r16) * CIN + q * 8) * 2u;
-  const char* xwg = (const char*)(x + xrow0 * CIN);
 
-  f32x4 acc[MTW][NTW];
-#pragma unroll
-  for (int i = 0; i < MTW; ++i)
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-
-  auto dma_x = [&](int c0, int buf) {
-    const char* src = xwg + c0 * 2;
+  // activation chunk c0.. of board group g -> buffer buf.  LDS slot (16 B) k of the image holds channel
+  // group k % 5 of padded row k / 5; slot 4 of a row is padding and re-fetches group 0, the tail of the
+  // last 1-KiB piece (and, in a ragged last group, the rows past the last board) re-fetches the last
+  // existing row.  The source offsets are recomputed per chunk (about 6 VALU per piece, once per nine
+  // stages) from an opaque lane id rather than kept in registers across the main loop.
+  auto dma_x = [&](int g, int c0, int buf) {
+    const long xrow0 = (long)g * XROWS;
+    const int rows_left = (int)min((long)XROWS, (long)B * PP - xrow0);
+    const char* src = (const char*)(x + xrow0 * CIN) + c0 * 2;
+    uint32_t slot0 = (uint32_t)(wave * 64 + lane);
+    asm volatile("" : "+v"(slot0));
 #pragma unroll
     for (int i = 0; i < NXW; ++i) {
       const int j = wave + 8 * i;
+      const uint32_t slot = slot0 + 512u * i;
+      uint32_t row = slot / 5u;
+      const uint32_t ch = slot - row * 5u;
+      row = min(row, (uint32_t)(rows_left - 1));
+      const uint32_t off = (row * CIN + (ch == 4 ? 0 : ch) * 8) * 2u;
       if (j < XI)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + xoff[i]),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
                                          (__attribute__((address_space(3))) void*)(sX + buf * XBYTES + j * 1024), 16, 0, 0);
     }
   };
@@ -255,18 +259,28 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
 
   const int nchunk = CIN / KC, nstage = nchunk * 9;
   const int nA = (AI - wave + 7) / 8, nX = (XI - wave + 7) / 8;   // pieces this wave issues per slice / chunk
-  // stage s = (chunk, tap) = (s / 9, s % 9); its weight slice lives in ring slot s % RING
-  auto dma_stage = [&](int s2) { const int c2 = s2 / 9; dma_a(s2 - c2 * 9, c2 * KC, s2 % RING); };
-  dma_x(0, 0);
-  for (int s2 = 0; s2 < 4 && s2 < nstage; ++s2) dma_stage(s2);
-  wait_vmcnt(nstage > 2 ? 2 * nA : 0);   // stages 0,1 (and the first chunk) have landed; 2,3 may still fly
+  const int total = nmine * nstage;    // stages of all this workgroup's board groups
+  // Weight slices are requested in global stage order; the slice of global stage t lives in ring slot
+  // t % RING (tracked incrementally: it_* describe the next stage to request).
+  int issued = 0, it_tap = 0, it_chunk = 0, it_slot = 0;
+  auto issue_next = [&]() {
+    dma_a(it_tap, it_chunk * KC, it_slot);
+    ++issued;
+    it_slot = it_slot + 1 == RING ? 0 : it_slot + 1;
+    if (++it_tap == 9) { it_tap = 0; if (++it_chunk == nchunk) it_chunk = 0; }
+  };
+  dma_x((int)blockIdx.x, 0, 0);
+  for (int s2 = 0; s2 < 4 && s2 < total; ++s2) issue_next();
+  wait_vmcnt(total > 2 ? 2 * nA : 0);   // stages 0,1 (and the first chunk) have landed; 2,3 may still fly
   __syncthreads();
   const char* Alane = sA + wc * MTW * 1024 + q * 256 + r16 * 16;
+
+  f32x4 acc[MTW][NTW];
   // one stage = one tap x 32 input channels: MTW x NTW MFMAs per wave
-  auto compute = [&](int s) {
-    const int chunk = s / 9, tap = s - chunk * 9, ty = tap / 3;
-    const char* A = Alane + (s % RING) * ABYTES;
-    const char* X = sX + (chunk & 1) * XBYTES + (ty * PW + (tap - ty * 3)) * 80;
+  auto compute = [&](int tap, int slot, int xbuf) {
+    const int ty = tap / 3;
+    const char* A = Alane + slot * ABYTES;
+    const char* X = sX + xbuf * XBYTES + (ty * PW + (tap - ty * 3)) * 80;
     bf16x8 a[MTW];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) a[mt] = *(const bf16x8*)(A + mt * 1024);
@@ -288,87 +302,116 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
       __builtin_amdgcn_sched_group_barrier(0x008, MTW, 0);
     }
   };
-  // Two stages per barrier.  At the top of a pair (s, s+1) the weight slices of stages s+4, s+5 are
-  // requested (ring of 6), and the next activation chunk when the pair contains tap 4; at the
-  // bottom the wave retires everything except what it requested in this pair (counted vmcnt),
-  // then a raw s_barrier publishes the pair s+2, s+3.  The loop stays rolled: stage-dependent
-  // offsets are wave-uniform scalars, an activation fragment read costs one v_add.
+
+  int G = 0;        // global stage index of the pair being computed
+  int gslot = 0;    // G % RING
+  int gchunk = 0;   // global chunk counter (activation buffer = gchunk & 1)
 #pragma unroll 1
-  for (int s = 0; s < nstage; s += 2) {
-    int inflight = 0;
-    if (s + 4 < nstage) { dma_stage(s + 4); inflight += nA; }
-    if (s + 5 < nstage) { dma_stage(s + 5); inflight += nA; }
-    {
-      const int chunk = s / 9, tap = s - chunk * 9;
-      if ((tap == 3 || tap == 4) && chunk + 1 < nchunk) { dma_x((chunk + 1) * KC, (chunk + 1) & 1); inflight += nX; }
+  for (int bi = 0; bi < nmine; ++bi) {
+    const int g = (int)blockIdx.x + bi * (int)gridDim.x;
+    const int board0 = g * NBW;
+    const long xrow0 = (long)g * XROWS;
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    // Two stages per barrier.  At the top of a pair the next one or two weight slices are requested
+    // (never more than 6 stages ahead of the pair: their ring slots were consumed before the last
+    // barrier), and the next activation chunk - of this board group or of the next - when the pair
+    // contains tap 4; at the bottom the wave retires everything except what it requested in this
+    // pair (counted vmcnt), then a raw s_barrier publishes the next pair.  The loop stays rolled:
+    // stage-dependent offsets are wave-uniform scalars, an activation fragment read costs one v_add.
+    int chunk = 0, tap = 0;
+#pragma unroll 1
+    for (int s = 0; s < nstage; s += 2) {
+      int inflight = 0;
+      if (issued < G + 6 && issued < total) { issue_next(); inflight += nA; }
+      if (issued < G + 6 && issued < total) { issue_next(); inflight += nA; }
+      if (tap == 3 || tap == 4) {
+        if (chunk + 1 < nchunk) { dma_x(g, (chunk + 1) * KC, (gchunk + 1) & 1); inflight += nX; }
+        else if (bi + 1 < nmine) { dma_x(g + (int)gridDim.x, 0, (gchunk + 1) & 1); inflight += nX; }
+      }
+      compute(tap, gslot, gchunk & 1);
+      ++G; gslot = gslot + 1 == RING ? 0 : gslot + 1;
+      if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
+      if (s + 1 < nstage) {
+        compute(tap, gslot, gchunk & 1);
+        ++G; gslot = gslot + 1 == RING ? 0 : gslot + 1;
+        if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
+      }
+      wait_vmcnt(inflight);
+      __builtin_amdgcn_s_barrier();
     }
-    compute(s);
-    if (s + 1 < nstage) compute(s + 1);
-    wait_vmcnt(inflight);
-    __builtin_amdgcn_s_barrier();
-  }
-  // epilogue: lane holds position r16 of each position tile, channels 4*q+reg of each channel tile.
-  // Channel tile outermost so that the bias (one float4) and the NTW residual words of a tile are
-  // all requested before the first is used (one memory latency per channel tile, not per word).
-  bool live[NTW];
-  size_t obase[NTW];
-#pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) {
-    const int p = (wp * NTW + nt) * 16 + r16;
-    live[nt] = p < PT && board0 + p / HW < B;
-    obase[nt] = (size_t)(xrow0 + (pb[nt] - q * 16) / 80 + (PW + 1)) * COUT;
-  }
-  // Software-pipelined over the channel tiles: the bias and residual words of tile mt+1 are requested
-  // BEFORE the stores of tile mt are issued.  vmcnt retires in order, so a load issued after stores
-  // could only be consumed once those stores had completed (a full HBM write round trip per tile).
-  auto load_tile = [&](int mt, float4& bv, uint2 (&rr)[NTW]) {
-    const int co = (wc * MTW + mt) * 16 + q * 4;
-    bv = *(const float4*)(bias + co);
-    if (res) {
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) rr[nt] = live[nt] ? *(const uint2*)(res + obase[nt] + co) : make_uint2(0, 0);
-    }
-  };
-  float4 bv_next; uint2 rr_next[NTW];
-  load_tile(0, bv_next, rr_next);
-#pragma unroll
-  for (int mt = 0; mt < MTW; ++mt) {
-    const int co = (wc * MTW + mt) * 16 + q * 4;
-    const float4 bv = bv_next;
-    uint2 rr[NTW];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) rr[nt] = rr_next[nt];
-    if (mt + 1 < MTW) load_tile(mt + 1, bv_next, rr_next);
-    uint2 o[NTW];
+    // epilogue: lane holds position r16 of each position tile, channels 4*q+reg of each channel tile.
+    // Channel tile outermost so that the bias (one float4) and the NTW residual words of a tile are
+    // all requested before the first is used (one memory latency per channel tile, not per word).
+    // Output addressing: wave-uniform base pointers of this board group + 32-bit per-lane element
+    // offsets, derived here from pb (through an opaque copy: hoisted out of the board loop they would
+    // sit in registers - or in scratch - across the whole main loop).
+    bool live[NTW];
+    uint32_t obase[NTW];
+    const uint16_t* const resg = res ? res + (size_t)xrow0 * COUT : nullptr;
+    uint16_t* const outg = out + (size_t)xrow0 * COUT;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-      float v[4] = {acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w};
+      const int p = (wp * NTW + nt) * 16 + r16;
+      live[nt] = p < PT && board0 + p / HW < B;
+      uint32_t pbv = (uint32_t)pb[nt];
+      asm volatile("" : "+v"(pbv));
+      obase[nt] = (pbv / 80u + (PW + 1)) * COUT;
+    }
+    // Software-pipelined over the channel tiles: the bias and residual words of tile mt+1 are requested
+    // BEFORE the stores of tile mt are issued.  vmcnt retires in order, so a load issued after stores
+    // could only be consumed once those stores had completed (a full HBM write round trip per tile).
+    auto load_tile = [&](int mt, float4& bv, uint2 (&rr)[NTW]) {
+      const int co = (wc * MTW + mt) * 16 + q * 4;
+      bv = *(const float4*)(bias + co);
       if (res) {
-        v[0] += bf2f((uint16_t)(rr[nt].x & 0xFFFF)); v[1] += bf2f((uint16_t)(rr[nt].x >> 16));
-        v[2] += bf2f((uint16_t)(rr[nt].y & 0xFFFF)); v[3] += bf2f((uint16_t)(rr[nt].y >> 16));
-      }
-      if (relu) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        for (int nt = 0; nt < NTW; ++nt) rr[nt] = live[nt] ? *(const uint2*)(resg + obase[nt] + co) : make_uint2(0, 0);
       }
-      o[nt].x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-      o[nt].y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-    }
-    // Stores are issue-bound, so make them 16 bytes wide: lanes q and q+1 (16 lanes apart) hold
-    // adjacent 4-channel groups.  v_permlane16_swap exchanges the odd 16-lane rows of one register
-    // with the even rows of another; applied to the words of a PAIR of position tiles it leaves
-    // rows 0/2 with channels [8(q/2), 8(q/2)+8) of the first tile and rows 1/3 with those of the second.
+    };
+    float4 bv_next; uint2 rr_next[NTW];
+    load_tile(0, bv_next, rr_next);
 #pragma unroll
-    for (int nt = 0; nt + 1 < NTW; nt += 2) {
-      const auto sx = __builtin_amdgcn_permlane16_swap(o[nt].x, o[nt + 1].x, false, false);
-      const auto sy = __builtin_amdgcn_permlane16_swap(o[nt].y, o[nt + 1].y, false, false);
-      const bool second = q & 1;
-      const uint4 st = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-      const size_t ob = second ? obase[nt + 1] : obase[nt];
-      if (second ? live[nt + 1] : live[nt]) *(uint4*)(out + ob + (wc * MTW + mt) * 16 + (q >> 1) * 8) = st;
-    }
-    if (NTW & 1) {
-      if (live[NTW - 1]) *(uint2*)(out + obase[NTW - 1] + co) = o[NTW - 1];
+    for (int mt = 0; mt < MTW; ++mt) {
+      const int co = (wc * MTW + mt) * 16 + q * 4;
+      const float4 bv = bv_next;
+      uint2 rr[NTW];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) rr[nt] = rr_next[nt];
+      if (mt + 1 < MTW) load_tile(mt + 1, bv_next, rr_next);
+      uint2 o[NTW];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        float v[4] = {acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w};
+        if (res) {
+          v[0] += bf2f((uint16_t)(rr[nt].x & 0xFFFF)); v[1] += bf2f((uint16_t)(rr[nt].x >> 16));
+          v[2] += bf2f((uint16_t)(rr[nt].y & 0xFFFF)); v[3] += bf2f((uint16_t)(rr[nt].y >> 16));
+        }
+        if (relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        o[nt].x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        o[nt].y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      }
+      // Stores are issue-bound, so make them 16 bytes wide: lanes q and q+1 (16 lanes apart) hold
+      // adjacent 4-channel groups.  v_permlane16_swap exchanges the odd 16-lane rows of one register
+      // with the even rows of another; applied to the words of a PAIR of position tiles it leaves
+      // rows 0/2 with channels [8(q/2), 8(q/2)+8) of the first tile and rows 1/3 with those of the second.
+#pragma unroll
+      for (int nt = 0; nt + 1 < NTW; nt += 2) {
+        const auto sx = __builtin_amdgcn_permlane16_swap(o[nt].x, o[nt + 1].x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(o[nt].y, o[nt + 1].y, false, false);
+        const bool second = q & 1;
+        const uint4 st = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        const uint32_t ob = second ? obase[nt + 1] : obase[nt];
+        if (second ? live[nt + 1] : live[nt]) *(uint4*)(outg + ob + (wc * MTW + mt) * 16 + (q >> 1) * 8) = st;
+      }
+      if (NTW & 1) {
+        if (live[NTW - 1]) *(uint2*)(outg + obase[NTW - 1] + co) = o[NTW - 1];
+      }
     }
   }
 }
@@ -575,6 +618,7 @@ struct NetImpl {
   float *fxin = nullptr, *fact[3] = {nullptr, nullptr, nullptr};
   bool loaded = false;
   bool use_board_kernel = true;   // ELFHIP_NET_TILE=positions selects the generic position-tiled kernel
+  int persist_wgs = 0;            // workgroups of the persistent board kernel (= CUs: the kernel's LDS allows one per CU); 0 = one per board group
   ~NetImpl() { for (void* p : allocs) (void)hipFree(p); }
 
   size_t param_count() const {
@@ -706,8 +750,10 @@ struct NetImpl {
       (void)hipFuncSetAttribute((const void*)conv3x3_board_kernel<COUT, H, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_board_kernel<COUT, H, NBW>), dim3((B + NBW - 1) / NBW), dim3(512), smem, stream, x, c.w, c.b, res,
-                       out, B, c.cin, relu);
+    const int ngroups = (B + NBW - 1) / NBW;
+    const int grid = persist_wgs > 0 ? std::min(ngroups, persist_wgs) : ngroups;
+    hipLaunchKernelGGL((conv3x3_board_kernel<COUT, H, NBW>), dim3(grid), dim3(512), smem, stream, x, c.w, c.b, res, out, B, c.cin,
+                       relu);
   }
   template <int COUT>
   bool conv_board(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
@@ -818,6 +864,13 @@ int elfhip_net_create(const elfhip_net_config* cfg, int max_batch, int device, e
   if (!n) { elfhip_set_error("net_create: host allocation failed"); return ELFHIP_ENOMEM; }
   n->cfg = *cfg; n->device = device; n->max_batch = max_batch;
   { const char* e = getenv("ELFHIP_NET_TILE"); if (e && !strcmp(e, "positions")) n->use_board_kernel = false; }
+  {
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, device));
+    n->persist_wgs = prop.multiProcessorCount;
+    const char* e = getenv("ELFHIP_NET_PERSIST");   // 0 = one workgroup per board group (A/B timing only)
+    if (e) n->persist_wgs = atoi(e);
+  }
   int rc = n->alloc();
   if (rc != ELFHIP_OK) { delete n; return rc; }
   *out = new elfhip_net{n};
