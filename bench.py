@@ -50,7 +50,7 @@ def cpu_baseline(threads=16, boards_per_thread=256, plies=8192):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=64)   # 64 launches x 4.19e6 moves = 2^28 moves
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--boards", type=int, default=BOARDS_PER_GPU)
     ap.add_argument("--plies", type=int, default=PLIES)
