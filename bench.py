@@ -63,11 +63,17 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if os.environ.get("ELF_BENCH_ONE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL ("nccl") over xGMI, one rank per GPU.  ELF_BENCH_BACKEND=gloo + ELF_BENCH_ONE_GPU=1 rehearse the
+        # multi-process path with every rank on GPU 0 (a one-GPU box cannot form an RCCL communicator).
+        backend = os.environ.get("ELF_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
