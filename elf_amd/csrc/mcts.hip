@@ -79,6 +79,7 @@ mcts_set_roots_kernel(TreeDev d, AmExtra x, int persistent, const uint64_t* __re
                       const uint32_t* __restrict__ hmeta, int n, uint8_t* __restrict__ ok) {
   const int t = blockIdx.x;
   if (threadIdx.x != 0) return;
+  if (d.t_flags[t] & FLAG_INACTIVE) { if (ok) ok[t] = 1; return; }
   if (!persistent) {
     TV c = tree_view(d, t, 0);
     init_node(c, 0, 0.f, -1, 0);
@@ -240,6 +241,7 @@ struct AmericanMcts : MctsBase {
     return ELFHIP_OK;
   }
   int select(uint64_t* d_leaf_states, float* d_leaf_features, uint8_t* d_need_eval) override {
+    { const int rc = zero_need(d_need_eval); if (rc != ELFHIP_OK) return rc; }
     hipLaunchKernelGGL(mcts_search_kernel<1>, dim3(d.n_trees), dim3(64), 0, stream, d, x, o, d_leaf_states,
                        d_leaf_features, d_need_eval, (const float*)nullptr, (const float*)nullptr);
     HIPCHECK(hipGetLastError());
@@ -363,6 +365,20 @@ int elfhip_mcts_pick_moves(elfhip_mcts* h, const int32_t* d_ply, int policy_dist
   mcts::MctsBase* m = h->m;
   hipLaunchKernelGGL(mcts::mcts_pick_kernel, dim3(m->d.n_trees), dim3(64), 0, m->stream, m->d, m->num_actions, d_ply,
                      policy_distri_cutoff, seed, counter, d_move, d_policy_u8, d_value);
+  HIPCHECK(hipGetLastError());
+  return ELFHIP_OK;
+}
+
+int elfhip_mcts_set_active(elfhip_mcts* h, const uint8_t* d_active) {
+  CHECK_M(h);
+  return h->m->set_active(d_active);
+}
+
+int elfhip_mcts_pick_policy_only(elfhip_mcts* h, const uint8_t* d_which, int16_t* d_move, float* d_value) {
+  CHECK_M(h);
+  if (!d_move) { elfhip_set_error("mcts_pick_policy_only: null d_move"); return ELFHIP_EINVAL; }
+  mcts::MctsBase* m = h->m;
+  hipLaunchKernelGGL(mcts::mcts_policy_only_kernel, dim3(m->d.n_trees), dim3(64), 0, m->stream, m->d, d_which, d_move, d_value);
   HIPCHECK(hipGetLastError());
   return ELFHIP_OK;
 }

@@ -21,7 +21,8 @@ constexpr int MAXB = 16;   // num_rollouts_per_batch limit
 enum { NOT_VISITED = 0, EVAL_REQUESTED = 1, VISITED = 2 };
 // node meta: status (bits 0..7) | flip << 8 | state_set << 9 | n_edges << 16
 constexpr uint32_t META_STATE_SET = 1u << 9, META_FLIP = 1u << 8;
-enum { FLAG_NODE_OVERFLOW = 1, FLAG_EDGE_OVERFLOW = 2, FLAG_DEPTH_OVERFLOW = 4, FLAG_LEGAL_OVERFLOW = 8, FLAG_ROOT_MISMATCH = 16 };
+enum { FLAG_NODE_OVERFLOW = 1, FLAG_EDGE_OVERFLOW = 2, FLAG_DEPTH_OVERFLOW = 4, FLAG_LEGAL_OVERFLOW = 8, FLAG_ROOT_MISMATCH = 16,
+       FLAG_INACTIVE = 32 };  // INACTIVE: another AI owns this game's move (elfhip_mcts_set_active); not an error
 
 struct Opt {
   int R, B, vl, use_prior; float c_puct; int uqz, ruqz, persistent, pick;
@@ -268,8 +269,18 @@ static __global__ void __launch_bounds__(64) mcts_clear_kernel(TreeDev d, const 
   TV tv = tree_view(d, t, 0);
   if (threadIdx.x == 0) {
     init_node(tv, 0, 0.f, -1, 0);
-    d.t_arena[t] = 0; d.t_nnodes[t] = 1; d.t_nedges[t] = 0; d.t_flags[t] = 0;
+    d.t_arena[t] = 0; d.t_nnodes[t] = 1; d.t_nedges[t] = 0; d.t_flags[t] &= FLAG_INACTIVE;
   }
+}
+
+// curr_ai = (white to move && _ai2) ? _ai2 : _ai1 (ClientGameSelfPlay.cc:344-346): only the AI that owns the
+// move searches.  Inactive trees are skipped by set_roots / noise / select / backup / pick; treeAdvance and
+// clear still apply (MCTSAI_T::advanceMoves replays the other side's moves, mcts.h:189-202).
+static __global__ void __launch_bounds__(64) mcts_set_active_kernel(TreeDev d, const uint8_t* __restrict__ active) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= d.n_trees) return;
+  const int f = d.t_flags[t] & ~FLAG_INACTIVE;
+  d.t_flags[t] = (active && !active[t]) ? (f | FLAG_INACTIVE) : f;
 }
 
 // chooseAction + MCTSResultT::addActions (tree_search.h:588-621, tree_search_base.h:310-367) and
@@ -332,6 +343,7 @@ static __global__ void __launch_bounds__(64)
 mcts_pick_kernel(TreeDev d, int NA, const int32_t* __restrict__ ply, int cutoff, uint64_t seed, uint64_t counter,
                  int16_t* __restrict__ move, uint8_t* __restrict__ pol, float* __restrict__ value) {
   const int t = blockIdx.x, lane = threadIdx.x;
+  if (d.t_flags[t] & FLAG_INACTIVE) return;  // the other AI's handle fills this game's outputs
   TV tv = tree_view(d, t, d.t_arena[t]);
   const uint32_t meta = tv.meta[0];
   const int ne = (meta & 0xFF) == VISITED ? (int)(meta >> 16) : 0;
@@ -376,6 +388,37 @@ mcts_pick_kernel(TreeDev d, int NA, const int32_t* __restrict__ ply, int cutoff,
   }
   if (lane == 0) {
     move[t] = chosen < 0 ? (int16_t)-1 : (int16_t)tv.ea[eb + chosen];
+    if (value) value[t] = (ne == 0 || total == 0) ? tv.V[0] : tv.er[eb + bestj] / (float)tv.ev[eb + bestj];
+  }
+}
+
+// MCTSAI_T::actPolicyOnly (mcts.h:107-113) after TreeSearchT::runPolicyOnly (tree_search.h:475-496): the
+// root's edges ranked by prior (MCTSResultT::addActions with PRIOR: first strict maximum in edge order),
+// value = MCTSGameAI::getValue (MCTSGameAI.h:40-46): root V while no edge has a visit, else reward /
+// num_visits of the chosen edge (0/0 = NaN when that edge itself is unvisited, as in the reference).
+static __global__ void __launch_bounds__(64)
+mcts_policy_only_kernel(TreeDev d, const uint8_t* __restrict__ which, int16_t* __restrict__ move, float* __restrict__ value) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  if ((which && !which[t]) || (d.t_flags[t] & FLAG_INACTIVE)) return;
+  TV tv = tree_view(d, t, d.t_arena[t]);
+  const uint32_t meta = tv.meta[0];
+  const int ne = (meta & 0xFF) == VISITED ? (int)(meta >> 16) : 0;
+  const int eb = (int)tv.ebase[0];
+  float best = -INFINITY; int bestj = 0x7FFFFFFF, total = 0;
+  for (int base = 0; base < ne; base += 64) {
+    const int j = base + lane; const bool ok = j < ne;
+    float s = ok ? tv.ep[eb + j] : -INFINITY; int sj = ok ? j : 0x7FFFFFFF; int sum = ok ? tv.ev[eb + j] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float s2 = __shfl_xor(s, off); const int j2 = __shfl_xor(sj, off);
+      if (s2 > s || (s2 == s && j2 < sj)) { s = s2; sj = j2; }
+      sum += __shfl_xor(sum, off);
+    }
+    if (s > best || (s == best && sj < bestj)) { best = s; bestj = sj; }
+    total += sum;
+  }
+  if (lane == 0) {
+    move[t] = ne == 0 ? (int16_t)-1 : (int16_t)tv.ea[eb + bestj];
     if (value) value[t] = (ne == 0 || total == 0) ? tv.V[0] : tv.er[eb + bestj] / (float)tv.ev[eb + bestj];
   }
 }
@@ -560,6 +603,16 @@ struct MctsBase {
     hipLaunchKernelGGL(mcts_root_noise_kernel, dim3(d.n_trees), dim3(64), 0, stream, d, epsilon, d_eta, d_off, d_cnt, d_Z);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(stream));  // the host vectors go out of scope
+    return ELFHIP_OK;
+  }
+  int set_active(const uint8_t* d_active) {
+    hipLaunchKernelGGL(mcts_set_active_kernel, dim3((d.n_trees + 63) / 64), dim3(64), 0, stream, d, d_active);
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  // parked and inactive trees leave their need_eval slots untouched: start every batch from zero
+  int zero_need(uint8_t* d_need_eval) {
+    if (d_need_eval) HIPCHECK(hipMemsetAsync(d_need_eval, 0, (size_t)d.n_trees * o.B, stream));
     return ELFHIP_OK;
   }
   int clear(const uint8_t* d_which) {

@@ -94,6 +94,7 @@ __global__ void __launch_bounds__(64)
 games_set_roots_kernel(TreeDev d, int persistent, const uint64_t* __restrict__ w, int n, uint8_t* __restrict__ ok) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= d.n_trees) return;
+  if (d.t_flags[t] & FLAG_INACTIVE) { if (ok) ok[t] = 1; return; }
   if (!persistent) {
     TV c = tree_view(d, t, 0);
     init_node(c, 0, 0.f, -1, 0);
@@ -203,6 +204,7 @@ struct GameMcts : MctsBase {
     return ELFHIP_OK;
   }
   int select(uint64_t* d_leaf_states, float* d_leaf_features, uint8_t* d_need_eval) override {
+    { const int rc = zero_need(d_need_eval); if (rc != ELFHIP_OK) return rc; }
     hipLaunchKernelGGL((games_search_kernel<G, 1>), dim3(d.n_trees), dim3(64), 0, stream, d, o, d_leaf_states,
                        d_leaf_features, d_need_eval, (const float*)nullptr, (const float*)nullptr);
     HIPCHECK(hipGetLastError());

@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(64)
 go_tree_set_roots_kernel(TreeDev d, GoDev g, int persistent, uint8_t* __restrict__ ok) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= d.n_trees) return;
+  if (d.t_flags[t] & FLAG_INACTIVE) { if (ok) ok[t] = 1; return; }
   if (!persistent) {
     TV c = tree_view(d, t, 0);
     init_node(c, 0, 0.f, -1, 0);

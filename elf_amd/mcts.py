@@ -110,6 +110,28 @@ class TreeSearchBatch:
             r["policy_visits"] = pol
         return r
 
+    def set_active(self, active=None):
+        """only trees with active[t] != 0 take part in set_roots / select / backup / picks until the next call
+        (the AI that owns the move, ClientGameSelfPlay.cc:344-346); None = all"""
+        assert active is None or (active.dtype == torch.uint8 and active.is_cuda and active.numel() == self.n)
+        check(self.L.elfhip_mcts_set_active(self.h, active.data_ptr() if active is not None else None))
+
+    def actPolicyOnly(self, evaluator, which=None):
+        """MCTSAI_T::actPolicyOnly (mcts.h:107-113) after set_roots: the root is evaluated once where it is not
+        visited yet (one select/backup batch does exactly that; trees whose root is already visited must be
+        masked out with set_active by the caller), then move = strongest prior, value = getValue."""
+        bs = self.info.board_size
+        st, ft, ne = self.select(want_states=True, want_features=True)
+        pi, v = evaluator(ft.view(self.n * self.B, self.info.num_planes, bs, bs), st, ne)
+        self.backup(pi.contiguous(), v.contiguous())
+        return self.pick_policy_only(which)
+
+    def pick_policy_only(self, which=None):
+        mv = torch.full((self.n,), -2, dtype=torch.int16, device=self.device)
+        val = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+        check(self.L.elfhip_mcts_pick_policy_only(self.h, which.data_ptr() if which is not None else None, mv.data_ptr(), val.data_ptr()))
+        return mv, val
+
     def treeAdvance(self, actions):
         assert actions.dtype == torch.int16 and actions.is_cuda and actions.numel() == self.n
         check(self.L.elfhip_mcts_advance(self.h, actions.data_ptr()))

@@ -192,6 +192,22 @@ int elfhip_mcts_result(elfhip_mcts* m, int16_t* d_best, int32_t* d_total_visits,
  * d_ply (nullable = never sample): i32 [n] current ply of each game (starts at 1 like getPly()). */
 int elfhip_mcts_pick_moves(elfhip_mcts* m, const int32_t* d_ply, int policy_distri_cutoff, uint64_t seed,
                            uint64_t counter, int16_t* d_move, uint8_t* d_policy_u8, float* d_value);
+/* Two AIs per game (ClientGameSelfPlay::restart, common/ClientGameSelfPlay.cc:155-196: _ai1 "actor_black", _ai2
+ * "actor_white" with its own c_puct / rollouts; :344-346 curr_ai = white to move && _ai2 ? _ai2 : _ai1): one
+ * elfhip_mcts handle per AI over the same games, and per move each handle searches only the games whose side
+ * to move it owns.  d_active u8 [n_trees] (nullable = all): trees with 0 are skipped by set_roots, root_noise,
+ * run_uniform, select (their need_eval slots read 0), backup, pick_moves and pick_policy_only (outputs left
+ * untouched, so two handles can fill one move array); clear and advance still apply to them - the idle AI
+ * replays the other side's moves into its own tree (MCTSAI_T::advanceMoves, mcts.h:189-202).  The mask stays
+ * until the next call.  elfhip_mcts_stats reports such trees with flag 32. */
+int elfhip_mcts_set_active(elfhip_mcts* m, const uint8_t* d_active);
+/* MCTSAI_T::actPolicyOnly (mcts.h:107-113; used when GameOptions.black/white_use_policy_network_only, 
+ * ClientGameSelfPlay.cc:340-352): after TreeSearchT::runPolicyOnly (tree_search.h:475-496 = evaluate the root
+ * once if it is not visited: ONE select/backup batch does exactly that on an unvisited root) the move is the
+ * root edge with the strongest prior (first strict maximum in edge order) and the recorded value is
+ * MCTSGameAI::getValue (MCTSGameAI.h:40-46).  d_which u8 [n_trees] (nullable = all) selects the trees;
+ * d_move i16 [n] (-1: root has no edges), d_value f32 [n] (nullable) are written for those only. */
+int elfhip_mcts_pick_policy_only(elfhip_mcts* m, const uint8_t* d_which, int16_t* d_move, float* d_value);
 /* TreeSearchT::treeAdvance (tree_search_node.h:458-474) with d_actions i16 [n_trees] (negative = skip). */
 int elfhip_mcts_advance(elfhip_mcts* m, const int16_t* d_actions);
 /* Counters since creation: h_stats4 = {rollouts, network evaluations, sum of descent depths, edges

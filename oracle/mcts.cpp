@@ -174,6 +174,7 @@ struct Mcts {
   long evals = 0, rollouts = 0, depth_sum = 0, edge_sum = 0;
   float root_epsilon = 0.f, root_alpha = 0.f;
   std::mt19937 rng;  // actors_[0]->rng()
+  bool policy_only = false;  // next run() = MCTSAI_T::actPolicyOnly -> TreeSearchT::runPolicyOnly (mcts.h:107-113)
 
   void enhance_exploration(Node* n) {  // tree_search_node.h:144-167
     if (root_epsilon == 0.0) return;
@@ -327,13 +328,25 @@ int run(Mcts<G>* m, const typename G::State* g, int max_edges, int* n_edges, uin
   auto* rootn = m->get(m->root);
   if (!rootn->state) rootn->state.reset(new State(*g));   // setRootNodeState
   if (!G::same(*rootn->state, *g)) return -2;              // "Root state is not the same"
-  if (m->root_epsilon > 0.0) m->enhance_exploration(rootn); // TreeSearchT::run tree_search.h:502-506
-  for (int idx = 0; idx < m->opt.num_rollouts; idx += m->opt.num_rollouts_per_batch) m->batch_rollouts(rootn);
+  if (m->policy_only) {
+    // TreeSearchT::runPolicyOnly tree_search.h:475-496: evaluate the root once if it is not visited
+    // yet, no noise, no rollouts; the result ranks the root's edges by prior (MCTSResult::PRIOR)
+    if (rootn->status != 2) {
+      Response r; m->evaluate(*rootn->state, &r);
+      for (auto& ap : r.pi) rootn->edges.insert(std::make_pair(ap.first, Edge(ap.second)));
+      m->edge_sum += (long)r.pi.size();
+      rootn->V = r.value; rootn->flip = r.q_flip; rootn->status = 2;
+    }
+  } else {
+    if (m->root_epsilon > 0.0) m->enhance_exploration(rootn); // TreeSearchT::run tree_search.h:502-506
+    for (int idx = 0; idx < m->opt.num_rollouts; idx += m->opt.num_rollouts_per_batch) m->batch_rollouts(rootn);
+  }
+  const int pick_method = m->policy_only ? 1 : m->opt.pick_method;
   // MCTSResultT::addActions tree_search_base.h:310-367
   float max_score = std::numeric_limits<float>::lowest();
   int best = 0, tv = 0, k = 0; const Edge* beste = nullptr;
   for (const auto& ap : rootn->edges) {
-    float score = m->opt.pick_method == 0 ? (float)ap.second.num_visits : ap.second.prior;
+    float score = pick_method == 0 ? (float)ap.second.num_visits : ap.second.prior;
     if (k < max_edges) { actions[k] = ap.first; visits[k] = ap.second.num_visits; rewards[k] = ap.second.reward; priors[k] = ap.second.prior; }
     ++k;
     tv += ap.second.num_visits;
@@ -355,6 +368,7 @@ using GoMcts = Mcts<GoTraits>;
 void* omcts_create(const int* iopt, float c_puct, int policy_kind, uint64_t policy_seed) { return create<AmTraits>(iopt, c_puct, policy_kind, policy_seed); }
 void omcts_set_callback(void* h, void (*cb)(const uint64_t*, float*, float*)) { ((AmMcts*)h)->policy_cb = cb; }
 void omcts_set_noise(void* h, float eps, float alpha, unsigned seed) { AmMcts* m = (AmMcts*)h; m->root_epsilon = eps; m->root_alpha = alpha; m->rng.seed(seed); }
+void omcts_set_policy_only(void* h, int on) { ((AmMcts*)h)->policy_only = on != 0; }
 void omcts_destroy(void* h) { delete (AmMcts*)h; }
 void omcts_clear(void* h) { ((AmMcts*)h)->clear(); }                       // MCTSAI_T::resetTree / endGame
 void omcts_advance(void* h, int action) { ((AmMcts*)h)->tree_advance((Action)action); }  // advanceMoves
@@ -363,6 +377,7 @@ void omcts_stats(void* h, long* out4) { AmMcts* m = (AmMcts*)h; out4[0] = m->rol
 void* ogomcts_create(const int* iopt, float c_puct, int policy_kind, uint64_t policy_seed) { return create<GoTraits>(iopt, c_puct, policy_kind, policy_seed); }
 void ogomcts_set_callback(void* h, void (*cb)(const uint64_t*, float*, float*)) { ((GoMcts*)h)->policy_cb = cb; }
 void ogomcts_set_noise(void* h, float eps, float alpha, unsigned seed) { GoMcts* m = (GoMcts*)h; m->root_epsilon = eps; m->root_alpha = alpha; m->rng.seed(seed); }
+void ogomcts_set_policy_only(void* h, int on) { ((GoMcts*)h)->policy_only = on != 0; }
 void ogomcts_destroy(void* h) { delete (GoMcts*)h; }
 void ogomcts_clear(void* h) { ((GoMcts*)h)->clear(); }
 void ogomcts_advance(void* h, int action) { ((GoMcts*)h)->tree_advance((Action)action); }
@@ -382,6 +397,7 @@ int omcts_run(void* h, const am_game* g, int max_edges, int* n_edges, uint16_t* 
   void* PRE##create(const int* iopt, float c_puct, int policy_kind, uint64_t policy_seed) { return create<TRAITS>(iopt, c_puct, policy_kind, policy_seed); } \
   void PRE##set_callback(void* h, void (*cb)(const uint64_t*, float*, float*)) { ((Mcts<TRAITS>*)h)->policy_cb = cb; }  \
   void PRE##set_noise(void* h, float eps, float alpha, unsigned seed) { auto* m = (Mcts<TRAITS>*)h; m->root_epsilon = eps; m->root_alpha = alpha; m->rng.seed(seed); } \
+  void PRE##set_policy_only(void* h, int on) { ((Mcts<TRAITS>*)h)->policy_only = on != 0; }                        \
   void PRE##destroy(void* h) { delete (Mcts<TRAITS>*)h; }                                                          \
   void PRE##clear(void* h) { ((Mcts<TRAITS>*)h)->clear(); }                                                        \
   void PRE##advance(void* h, int action) { ((Mcts<TRAITS>*)h)->tree_advance((Action)action); }                      \

@@ -449,6 +449,12 @@ class OracleMcts:
         f.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint]
         f(self.h, eps, alpha, seed)
 
+    def set_policy_only(self, on):
+        """the next run() calls are MCTSAI_T::actPolicyOnly (root evaluation only, edges ranked by prior)"""
+        f = getattr(self.L, self.pre + "set_policy_only")
+        f.argtypes = [C.c_void_p, C.c_int]
+        f(self.h, int(bool(on)))
+
     def advance(self, a):
         getattr(self.L, self.pre + "advance")(self.h, int(a))
 
