@@ -11,13 +11,20 @@
 //   -> pick move / diverse move / record policy + value -> forward -> treeAdvance
 //   -> finished games: final value, win statistics, record, tree reset, restart, one "game_end"
 //      batch per finished game (GameNotifier::OnGameEnd, common/DistriClient.h:285-298).
-// Control plane (ZMQ dispatcher, model-version requests from a server) is out of scope: games start
-// with start(); DistriClient.setRequest only chooses one model (white_ver < 0) or two.
+// Requests (MsgRequest = ModelPair + ClientCtrl, common/record.h:40-198, ModelPair.h:22-78) arrive through
+// DistriClient.setRequest (what selfplay.py calls) or DistriClient.onRequestJson (the MsgRequest JSON a
+// server sends; the ZMQ transport itself is out of scope) and go through ClientGameSelfPlay::OnReceive's
+// decisions (ClientGameSelfPlay.cc:198-247): wait / restart with new AIs / update request only / async.
+// Two models: _ai1 and _ai2 are separate searches with their own trees (one elfhip_mcts handle each,
+// elfhip_mcts_set_active), white overrides (white_puct, white_mcts_rollout_per_*), player_swap.
+// black/white_use_policy_network_only -> actPolicyOnly.  mode "play": the human side is served through
+// the "actor_white" batch (reply key "a": move, -100 not yet, -1 end game, -2 switch sides and end).
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <array>
 #include <cstdlib>
 #include <cstring>
@@ -123,11 +130,30 @@ struct GameRecord {  // what GuardedRecords keeps per finished game (game/Record
 
 class SelfPlayEngine;
 
-struct DistriClient {  // common/DistriClient.h:322-403 (only what selfplay.py touches)
+struct MsgRequest {  // common/record.h: vers (ModelPair) + client_ctrl (ClientCtrl)
+  long long black_ver = -1, white_ver = -1;
+  TSOptions mcts_opt;
+  int client_type = 1;  // CLIENT_SELFPLAY_ONLY
+  int num_game_thread_used = -1;
+  bool player_swap = false, async = false;
+  bool wait() const { return black_ver < 0; }                               // ModelPair::wait
+  bool is_selfplay() const { return black_ver >= 0 && white_ver == -1; }    // ModelPair::is_selfplay
+};
+static bool same_ts(const TSOptions& a, const TSOptions& b) {  // TSOptions::operator== (tree_search_options.h)
+  return a.max_num_moves == b.max_num_moves && a.num_threads == b.num_threads &&
+         a.num_rollouts_per_thread == b.num_rollouts_per_thread && a.num_rollouts_per_batch == b.num_rollouts_per_batch &&
+         a.verbose == b.verbose && a.verbose_time == b.verbose_time && a.persistent_tree == b.persistent_tree &&
+         a.root_epsilon == b.root_epsilon && a.root_alpha == b.root_alpha && a.pick_method == b.pick_method &&
+         a.virtual_loss == b.virtual_loss && a.alg_opt.use_prior == b.alg_opt.use_prior && a.alg_opt.c_puct == b.alg_opt.c_puct &&
+         a.alg_opt.unexplored_q_zero == b.alg_opt.unexplored_q_zero && a.alg_opt.root_unexplored_q_zero == b.alg_opt.root_unexplored_q_zero;
+}
+
+struct DistriClient {  // common/DistriClient.h:322-403 (what selfplay.py touches) + the request a server would send
   SelfPlayEngine* eng = nullptr;
   GameStats stats;
   long long black_ver = -1, white_ver = -1;
   void setRequest(long long black, long long white, int num_threads);
+  std::string onRequestJson(const std::string& js);
   GameStats& getGameStats() { return stats; }
 };
 
@@ -144,11 +170,13 @@ class SelfPlayEngine : public elfhip_py::Engine {
   SelfPlayEngine(int game, const ContextOptions& co, const GameOptions& go) : game_(game), co_(co), go_(go) {
     ck(elfhip_game_get_info(game, &gi_), "game_get_info");
     if (go.mode != "selfplay" && go.mode != "play" && !go.mode.empty())
-      throw std::range_error("GameContext: mode '" + go.mode + "' is not built (self-play hot path only: selfplay)");
+      throw std::range_error("GameContext: mode '" + go.mode + "' is not built (self-play hot path only: selfplay, play)");
     if (co.num_games <= 0) throw std::range_error("GameContext: num_games must be positive");
     const char* dv = std::getenv("ELFHIP_DEVICE");
     device_ = dv ? std::atoi(dv) : 0;
     client_.eng = this;
+    req_.mcts_opt = co_.mcts_options;
+    human_for_ = go_.human_plays_for;
     games_.resize(co.num_games);
     for (int i = 0; i < co.num_games; ++i) { games_[i].eng = this; games_[i].idx = i; }
   }
@@ -194,39 +222,26 @@ class SelfPlayEngine : public elfhip_py::Engine {
   void start() override {
     if (!label("actor_black"))
       throw std::runtime_error("GameContext: no 'actor_black' batch was allocated (game.py:383-397)");
-    const TSOptions& t = co_.mcts_options;
-    if (t.pick_method != "most_visited" && t.pick_method != "strongest_prior")
-      throw std::range_error("MCTS Pick method unknown! " + t.pick_method);  // tree_search.h:615
+    if (play_mode() && !label("actor_white"))
+      throw std::runtime_error("GameContext: mode 'play' needs an 'actor_white' batch for the human side (game.py:346-363)");
     hk(hipSetDevice(device_), "hipSetDevice");
     n_ = co_.num_games;
-    B_ = t.num_rollouts_per_batch;
-    // search threads are serialised: num_threads x num_rollouts_per_thread rollouts on one "thread"
-    // (the reference's result is only defined run-to-run for num_threads == 1)
-    R_ = t.num_rollouts_per_thread * (t.num_threads > 0 ? t.num_threads : 1);
-    elfhip_ts_options o{R_, B_, t.virtual_loss, t.alg_opt.use_prior ? 1 : 0, t.alg_opt.c_puct,
-                        t.alg_opt.unexplored_q_zero ? 1 : 0, t.alg_opt.root_unexplored_q_zero ? 1 : 0,
-                        t.persistent_tree ? 1 : 0, t.pick_method == "most_visited" ? 0 : 1, 0, 0};
     ck(elfhip_boards_create(game_, n_, device_, &boards_), "boards_create");
-    ck(elfhip_mcts_create(game_, n_, &o, device_, &mcts_), "mcts_create");
-    {  // the reference seeds each game's rng with GameOptions.seed (GameBase.h:43-49) and the actor's with its first draw
-      std::vector<uint32_t> seeds(n_);
-      for (int i = 0; i < n_; ++i) { std::mt19937 g(go_.seed + (unsigned)i); seeds[i] = (uint32_t)g(); }
-      ck(elfhip_mcts_seed_rng(mcts_, seeds.data()), "mcts_seed_rng");
-    }
-    const size_t slots = (size_t)n_ * B_, A = gi_.num_actions;
+    build_ais();
+    const size_t A = gi_.num_actions;
     feat_row_ = (size_t)gi_.num_planes * gi_.board_size * gi_.board_size * 4;
     max_chunk_ = 1;
     for (auto& kv : by_label_) for (auto* m : kv.second) max_chunk_ = std::max(max_chunk_, m->opts.batchsize);
-    dmalloc(&d_feat_, slots * feat_row_); dmalloc(&d_need_, slots); dmalloc(&d_pi_, slots * A * 4); dmalloc(&d_v_, slots * 4);
-    dmalloc(&d_idx_, slots * 4); dmalloc(&d_cfeat_, (size_t)max_chunk_ * feat_row_); dmalloc(&d_cpi_, (size_t)max_chunk_ * A * 4);
+    dmalloc(&d_idx_, (size_t)n_ * 16 * 4); dmalloc(&d_cfeat_, (size_t)max_chunk_ * feat_row_); dmalloc(&d_cpi_, (size_t)max_chunk_ * A * 4);
     dmalloc(&d_cv_, (size_t)max_chunk_ * 4);
     dmalloc(&d_move_, (size_t)n_ * 2); dmalloc(&d_pol_, (size_t)n_ * A); dmalloc(&d_val_, (size_t)n_ * 4);
     dmalloc(&d_ply_, (size_t)n_ * 4); dmalloc(&d_ok_, (size_t)n_); dmalloc(&d_term_, (size_t)n_);
     dmalloc(&d_mask_, (size_t)n_ * gi_.mask_words * 8); dmalloc(&d_reward_, (size_t)n_ * 4);
-    hk(hipMemset(d_pi_, 0, slots * A * 4), "memset"); hk(hipMemset(d_v_, 0, slots * 4), "memset");
-    h_need_.resize(slots); h_states_.resize((size_t)n_ * gi_.state_words); h_ply_.assign(n_, 1); h_player_.assign(n_, 0);
+    dmalloc(&d_m8_, (size_t)n_); dmalloc(&d_nedges_, (size_t)n_ * 4); dmalloc(&d_bfeat_, (size_t)n_ * feat_row_);
+    h_states_.resize((size_t)n_ * gi_.state_words); h_ply_.assign(n_, 1); h_player_.assign(n_, 0);
     h_move_.resize(n_); h_val_.resize(n_); h_pol_.resize((size_t)n_ * A); h_ok_.resize(n_); h_term_.resize(n_); h_reward_.resize(n_);
-    h_cv_.resize(max_chunk_); h_cpi_.resize((size_t)max_chunk_ * A);
+    h_owner_.assign(n_, 0); h_ponly_.assign(n_, 0); h_human_.assign(n_, 0); h_m8_.resize(n_); h_nedges_.resize(n_);
+    h_hmove_.assign(n_, -1); h_force_end_.assign(n_, 0); h_skip_.assign(n_, 0);
     cur_.assign(n_, GameRecord()); seq_.assign(n_, 0);
     refresh_states();
     phase_ = BEGIN;
@@ -240,6 +255,9 @@ class SelfPlayEngine : public elfhip_py::Engine {
       if (!out_.empty()) { SharedMem* m = out_.front(); out_.pop_front(); return m; }
       switch (phase_) {
         case BEGIN:
+          // do { checkMessage } while (currRequest().vers.wait())  (ClientGameSelfPlay.cc:255-257): a waiting
+          // client produces nothing; the caller's wait() comes back empty, as after a timeout
+          if (waiting_) return nullptr;
           if (restart_pending_) {  // OnReceive -> restart() -> UPDATE_MODEL -> one "game_start" batch
             restart_pending_ = false;  // (ClientGameSelfPlay.cc:198-247, DispatcherCallback.h:61-111)
             restart_all();
@@ -252,35 +270,33 @@ class SelfPlayEngine : public elfhip_py::Engine {
               break;
             }
           }
-          ck(elfhip_mcts_set_roots(mcts_, boards_, nullptr), "mcts_set_roots");
-          if (co_.mcts_options.root_epsilon > 0.0f)  // TreeSearchT::run, tree_search.h:502-506
-            ck(elfhip_mcts_root_noise(mcts_, co_.mcts_options.root_epsilon, co_.mcts_options.root_alpha), "mcts_root_noise");
-          rollouts_ = 0;
-          phase_ = SELECT;
+          begin_move();
           break;
+        case HUMAN: return serve_human();
         case SELECT: {
-          if (rollouts_ >= R_) { phase_ = MOVE; break; }
-          ck(elfhip_mcts_select(mcts_, nullptr, (float*)d_feat_, (uint8_t*)d_need_), "mcts_select");
+          if (job_ >= jobs_.size()) { phase_ = MOVE; break; }
+          const Job& jb = jobs_[job_];
+          if (rollouts_ == 0) set_active(jb.ai, jb.mask);
+          if (rollouts_ >= jb.need) { ++job_; rollouts_ = 0; break; }
+          const int B = spec_[jb.ai].B;
+          ck(elfhip_mcts_select(mcts_[jb.ai], nullptr, (float*)d_feat_, (uint8_t*)d_need_), "mcts_select");
+          h_need_.resize((size_t)n_ * B);
           hk(hipMemcpy(h_need_.data(), d_need_, h_need_.size(), hipMemcpyDeviceToHost), "copy need");
-          // leaves that go to the network, split by which AI owns the tree's root
-          // (curr_ai = white && _ai2 ? _ai2 : _ai1, ClientGameSelfPlay.cc:344-346)
-          pend_[0].clear(); pend_[1].clear();
-          for (size_t s = 0; s < h_need_.size(); ++s)
-            if (h_need_[s]) pend_[(two_models() && h_player_[s / B_] == 1) ? 1 : 0].push_back((int32_t)s);
           h_idx_.clear();
-          h_idx_.insert(h_idx_.end(), pend_[0].begin(), pend_[0].end());
-          h_idx_.insert(h_idx_.end(), pend_[1].begin(), pend_[1].end());
+          for (size_t s = 0; s < h_need_.size(); ++s) if (h_need_[s]) h_idx_.push_back((int32_t)s);
           if (!h_idx_.empty()) hk(hipMemcpy(d_idx_, h_idx_.data(), h_idx_.size() * 4, hipMemcpyHostToDevice), "copy idx");
           cursor_ = 0;
           phase_ = h_idx_.empty() ? BACKUP : SERVE;
           break;
         }
         case SERVE: return serve_chunk();
-        case BACKUP:
-          ck(elfhip_mcts_backup(mcts_, (const float*)d_pi_, (const float*)d_v_), "mcts_backup");
-          rollouts_ += B_;
+        case BACKUP: {
+          const Job& jb = jobs_[job_];
+          ck(elfhip_mcts_backup(mcts_[jb.ai], (const float*)d_pi_, (const float*)d_v_), "mcts_backup");
+          rollouts_ += spec_[jb.ai].B;
           phase_ = SELECT;
           break;
+        }
         case MOVE:
           make_moves();
           phase_ = BEGIN;
@@ -293,6 +309,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
     if (m != serving_) return;  // game_end and other reply-less batches
     serving_ = nullptr;
     hk(hipSetDevice(device_), "hipSetDevice");
+    if (phase_ == HUMAN) { human_reply(m, success); return; }
     const int k = chunk_n_;
     const size_t A = gi_.num_actions;
     AnyP* pi = key(m, "pi");
@@ -314,15 +331,30 @@ class SelfPlayEngine : public elfhip_py::Engine {
 
   void stop() override { running_ = false; release(); }
 
-  // DistriClient::setRequest: a request whose versions differ from the current ones restarts every game
-  // at the next move boundary (the reference's games poll their mailbox between moves)
-  void on_request(long long black, long long white) {
-    const bool same = black == client_.black_ver && white == client_.white_ver;
-    client_.black_ver = black; client_.white_ver = white;
-    if (running_ && !same) restart_pending_ = true;
+  // ClientGameSelfPlay::OnReceive (ClientGameSelfPlay.cc:198-247) for ALL games at once (the reference's games
+  // poll the same mailbox between moves; here the decision takes effect at the next move boundary).
+  // Returns the RestartReply the reference's game would give (DispatcherCallback.h).
+  std::string on_request(const MsgRequest& r) {
+    const bool is_waiting = r.wait(), is_prev_waiting = req_.wait();
+    const bool same_vers = r.black_ver == req_.black_ver && r.white_ver == req_.white_ver && same_ts(r.mcts_opt, req_.mcts_opt);
+    const bool same_player_swap = r.player_swap == req_.player_swap;
+    const bool no_restart = (same_vers || r.async) && same_player_swap && !is_prev_waiting;
+    req_ = r;
+    client_.black_ver = r.black_ver; client_.white_ver = r.white_ver;
+    if (is_waiting) { waiting_ = true; return "ONLY_WAIT"; }
+    waiting_ = false;
+    if (!no_restart) {
+      if (running_) restart_pending_ = true;
+      return "UPDATE_MODEL";
+    }
+    if (!r.async) return "UPDATE_REQUEST_ONLY";
+    // setAsync: the AIs stop insisting on a model version (required_version = -1); versions are not
+    // checked on this side of the boundary, so only the bookkeeping changes
+    return same_vers ? "UPDATE_REQUEST_ONLY" : "UPDATE_MODEL_ASYNC";
   }
+  const MsgRequest& request() const { return req_; }
   void restart_all() {
-    ck(elfhip_mcts_clear(mcts_, nullptr), "mcts_clear");
+    build_ais();
     ck(elfhip_boards_reset(boards_), "boards_reset");
     for (auto& r : cur_) r = GameRecord();
     refresh_states();
@@ -367,7 +399,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
   // white_ver,mcts_opt{...}},client_ctrl{...}}, result{num_move,reward,using_models,content,policies,
   // values}, timestamp, thread_id, seq, pri, offline; moves as "(;[12];[98])" (sgf/sgf.h:34-41).
   py::dict request_dict() const {
-    const TSOptions& t = co_.mcts_options;
+    const TSOptions& t = req_.mcts_opt;
     py::dict alg, mo, vers, cc, req;
     alg["use_prior"] = t.alg_opt.use_prior; alg["c_puct"] = t.alg_opt.c_puct;
     alg["unexplored_q_zero"] = t.alg_opt.unexplored_q_zero; alg["root_unexplored_q_zero"] = t.alg_opt.root_unexplored_q_zero;
@@ -376,9 +408,9 @@ class SelfPlayEngine : public elfhip_py::Engine {
     mo["verbose"] = t.verbose; mo["verbose_time"] = t.verbose_time; mo["seed"] = t.seed; mo["persistent_tree"] = t.persistent_tree;
     mo["pick_method"] = t.pick_method; mo["log_prefix"] = t.log_prefix; mo["root_epsilon"] = t.root_epsilon;
     mo["root_alpha"] = t.root_alpha; mo["virtual_loss"] = t.virtual_loss; mo["alg_opt"] = alg;
-    vers["black_ver"] = client_.black_ver; vers["white_ver"] = client_.white_ver; vers["mcts_opt"] = mo;
-    cc["client_type"] = client_.white_ver >= 0 ? 2 : 1;  // CLIENT_EVAL_THEN_SELFPLAY : CLIENT_SELFPLAY_ONLY (common/record.h:30-34)
-    cc["num_game_thread_used"] = -1; cc["player_swap"] = false; cc["async"] = false;
+    vers["black_ver"] = req_.black_ver; vers["white_ver"] = req_.white_ver; vers["mcts_opt"] = mo;
+    cc["client_type"] = req_.client_type;  // CLIENT_SELFPLAY_ONLY 1 / CLIENT_EVAL_THEN_SELFPLAY 2 (common/record.h:30-34)
+    cc["num_game_thread_used"] = req_.num_game_thread_used; cc["player_swap"] = req_.player_swap; cc["async"] = req_.async;
     req["vers"] = vers; req["client_ctrl"] = cc;
     return req;
   }
@@ -408,27 +440,146 @@ class SelfPlayEngine : public elfhip_py::Engine {
   }
   py::dict search_stats() {
     need_running();
-    unsigned long long st[4];
-    ck(elfhip_mcts_stats(mcts_, st, nullptr), "mcts_stats");
+    unsigned long long st[4] = {0, 0, 0, 0};
+    for (int k = 0; k < n_ai_; ++k) {
+      unsigned long long s1[4];
+      ck(elfhip_mcts_stats(mcts_[k], s1, nullptr), "mcts_stats");
+      for (int j = 0; j < 4; ++j) st[j] += s1[j];
+    }
     py::dict d;
     d["rollouts"] = st[0]; d["evals"] = st[1]; d["depth_sum"] = st[2]; d["edge_sum"] = st[3];
     return d;
   }
-  bool two_models() { return client_.white_ver >= 0 && label("actor_white"); }
+  // which AIs exist and what they run with (ClientGameSelfPlay::restart / init_ai)
+  py::list ai_info() const {
+    py::list l;
+    for (int k = 0; k < n_ai_; ++k) {
+      py::dict d;
+      d["actor"] = spec_[k].label; d["version"] = spec_[k].ver; d["c_puct"] = spec_[k].c_puct;
+      d["num_rollouts_per_thread"] = spec_[k].R; d["num_rollouts_per_batch"] = spec_[k].B;
+      d["plays"] = n_ai_ == 1 ? "both" : (k == 0 ? "black" : "white");
+      l.append(d);
+    }
+    return l;
+  }
+  bool two_models() { return !play_mode() && req_.white_ver >= 0 && label("actor_white"); }
+  bool play_mode() const { return go_.mode == "play"; }
 
  private:
-  enum Phase { BEGIN, SELECT, SERVE, BACKUP, MOVE };
+  enum Phase { BEGIN, HUMAN, SELECT, SERVE, BACKUP, MOVE };
+  struct AiSpec { std::string label; long long ver = -1; float c_puct = 0; int R = 1, B = 1; };
+  struct Job { int ai; std::vector<uint8_t> mask; int need; };
 
   void need_running() const { if (!running_) throw std::runtime_error("GameContext: context is not running"); }
   void dmalloc(void** p, size_t bytes) {
     hk(hipMalloc(p, bytes ? bytes : 4), "hipMalloc");
     allocs_.push_back(*p);
   }
+  void dfree(void*& p) {
+    if (!p) return;
+    allocs_.erase(std::remove(allocs_.begin(), allocs_.end(), p), allocs_.end());
+    (void)hipFree(p);
+    p = nullptr;
+  }
   void release() {
-    if (mcts_) { elfhip_mcts_destroy(mcts_); mcts_ = nullptr; }
+    for (auto& m : mcts_) if (m) { elfhip_mcts_destroy(m); m = nullptr; }
     if (boards_) { elfhip_boards_destroy(boards_); boards_ = nullptr; }
     for (void* p : allocs_) (void)hipFree(p);
     allocs_.clear();
+  }
+
+  // ClientGameSelfPlay::restart (ClientGameSelfPlay.cc:155-196) + init_ai (:41-92): _ai1 "actor_black" with the
+  // request's mcts_opt; with white_ver >= 0 _ai2 "actor_white" with white_puct / white_mcts_rollout_per_batch /
+  // white_mcts_rollout_per_thread overrides; swapped when the request is an evaluation with player_swap.
+  // Each AI is its own elfhip_mcts handle (own trees).  Search threads are serialised: num_threads x
+  // num_rollouts_per_thread rollouts on one "thread" (results are only defined run-to-run for num_threads == 1).
+  void build_ais() {
+    const TSOptions& t = req_.mcts_opt;
+    if (t.pick_method != "most_visited" && t.pick_method != "strongest_prior")
+      throw std::range_error("MCTS Pick method unknown! " + t.pick_method);  // tree_search.h:615
+    const int threads = t.num_threads > 0 ? t.num_threads : 1;
+    AiSpec a1{"actor_black", req_.black_ver, t.alg_opt.c_puct, t.num_rollouts_per_thread * threads, t.num_rollouts_per_batch};
+    n_ai_ = 1;
+    spec_[0] = a1;
+    if (two_models()) {
+      AiSpec a2 = a1;
+      a2.label = "actor_white"; a2.ver = req_.white_ver;
+      if (go_.white_puct > 0.0f) a2.c_puct = go_.white_puct;
+      if (go_.white_mcts_rollout_per_batch > 0) a2.B = go_.white_mcts_rollout_per_batch;
+      if (go_.white_mcts_rollout_per_thread > 0) a2.R = go_.white_mcts_rollout_per_thread * threads;
+      spec_[1] = a2;
+      n_ai_ = 2;
+      if (!req_.is_selfplay() && req_.player_swap) std::swap(spec_[0], spec_[1]);
+    }
+    int maxB = 1;
+    for (int k = 0; k < 2; ++k) if (mcts_[k]) { elfhip_mcts_destroy(mcts_[k]); mcts_[k] = nullptr; }
+    for (int k = 0; k < n_ai_; ++k) {
+      elfhip_ts_options o{spec_[k].R, spec_[k].B, t.virtual_loss, t.alg_opt.use_prior ? 1 : 0, spec_[k].c_puct,
+                          t.alg_opt.unexplored_q_zero ? 1 : 0, t.alg_opt.root_unexplored_q_zero ? 1 : 0,
+                          t.persistent_tree ? 1 : 0, t.pick_method == "most_visited" ? 0 : 1, 0, 0};
+      ck(elfhip_mcts_create(game_, n_, &o, device_, &mcts_[k]), "mcts_create");
+      // the reference seeds each game's rng with GameOptions.seed (GameBase.h:43-49); init_ai hands every new
+      // AI the game rng's next draw as MCTSActorParams::seed: first draw -> _ai1, second -> _ai2
+      std::vector<uint32_t> seeds(n_);
+      for (int i = 0; i < n_; ++i) {
+        std::mt19937 g(go_.seed + (unsigned)i);
+        uint32_t v = (uint32_t)g();
+        if (k == 1) v = (uint32_t)g();
+        seeds[i] = v;
+      }
+      ck(elfhip_mcts_seed_rng(mcts_[k], seeds.data()), "mcts_seed_rng");
+      maxB = std::max(maxB, spec_[k].B);
+    }
+    if (maxB > slotB_) {  // leaf-slot arrays are shared by the AIs (one select/backup batch is in flight at a time)
+      dfree(d_feat_); dfree(d_need_); dfree(d_pi_); dfree(d_v_);
+      const size_t slots = (size_t)n_ * maxB, A = gi_.num_actions;
+      const size_t frow = (size_t)gi_.num_planes * gi_.board_size * gi_.board_size * 4;
+      dmalloc(&d_feat_, slots * frow); dmalloc(&d_need_, slots); dmalloc(&d_pi_, slots * A * 4); dmalloc(&d_v_, slots * 4);
+      hk(hipMemset(d_pi_, 0, slots * A * 4), "memset"); hk(hipMemset(d_v_, 0, slots * 4), "memset");
+      slotB_ = maxB;
+    }
+  }
+
+  void set_active(int ai, const std::vector<uint8_t>& mask) {
+    hk(hipMemcpy(d_m8_, mask.data(), (size_t)n_, hipMemcpyHostToDevice), "copy mask");
+    ck(elfhip_mcts_set_active(mcts_[ai], (const uint8_t*)d_m8_), "mcts_set_active");
+  }
+  static bool any(const std::vector<uint8_t>& m) { for (uint8_t x : m) if (x) return true; return false; }
+
+  // One move of every game (ClientGameSelfPlay::act, :249-375): who moves (human / which AI / policy only),
+  // roots, root noise, and the list of search jobs that the SELECT phase works through.
+  void begin_move() {
+    jobs_.clear(); job_ = 0; rollouts_ = 0;
+    bool any_human = false, any_ponly = false;
+    for (int i = 0; i < n_; ++i) {
+      const int pl = h_player_[i];
+      h_human_[i] = (play_mode() && pl == human_for_) ? 1 : 0;
+      h_owner_[i] = (n_ai_ == 2 && pl == 1) ? 1 : 0;   // curr_ai = white && _ai2 ? _ai2 : _ai1  (:344-346)
+      h_ponly_[i] = (!h_human_[i] && ((pl == 1 && go_.white_use_policy_network_only) ||
+                                      (pl == 0 && go_.black_use_policy_network_only))) ? 1 : 0;   // :340-342
+      any_human = any_human || h_human_[i];
+      any_ponly = any_ponly || h_ponly_[i];
+      h_hmove_[i] = -1; h_force_end_[i] = 0;
+    }
+    for (int k = 0; k < n_ai_; ++k) {
+      std::vector<uint8_t> own(n_), search(n_), fresh(n_, 0);
+      for (int i = 0; i < n_; ++i) { own[i] = (!h_human_[i] && h_owner_[i] == k) ? 1 : 0; search[i] = own[i] && !h_ponly_[i]; }
+      set_active(k, own);
+      ck(elfhip_mcts_set_roots(mcts_[k], boards_, nullptr), "mcts_set_roots");
+      if (any_ponly) {  // runPolicyOnly evaluates the root only if the persistent tree has not visited it yet
+        ck(elfhip_mcts_result(mcts_[k], nullptr, nullptr, nullptr, nullptr, (int32_t*)d_nedges_, nullptr, nullptr, nullptr, nullptr, 0,
+                              nullptr), "mcts_result");
+        hk(hipMemcpy(h_nedges_.data(), d_nedges_, (size_t)n_ * 4, hipMemcpyDeviceToHost), "copy nedges");
+        for (int i = 0; i < n_; ++i) fresh[i] = (own[i] && h_ponly_[i] && h_nedges_[i] == 0) ? 1 : 0;
+      }
+      if (req_.mcts_opt.root_epsilon > 0.0f && any(search)) {  // TreeSearchT::run, tree_search.h:502-506
+        set_active(k, search);
+        ck(elfhip_mcts_root_noise(mcts_[k], req_.mcts_opt.root_epsilon, req_.mcts_opt.root_alpha), "mcts_root_noise");
+      }
+      if (any(search)) jobs_.push_back(Job{k, search, spec_[k].R});
+      if (any(fresh)) jobs_.push_back(Job{k, fresh, 1});   // one batch on an unvisited root = its evaluation
+    }
+    phase_ = any_human ? HUMAN : SELECT;
   }
 
   SharedMem* pick_smem(const std::string& label) {  // num_recv buffers per label are used in turn (game.py:428)
@@ -439,10 +590,10 @@ class SelfPlayEngine : public elfhip_py::Engine {
   }
 
   SharedMem* serve_chunk() {
-    const bool white = cursor_ >= pend_[0].size();
-    const size_t end = white ? h_idx_.size() : pend_[0].size();
-    SharedMem* m = pick_smem(white ? "actor_white" : "actor_black");
-    const int k = (int)std::min<size_t>((size_t)m->opts.batchsize, end - cursor_);
+    const Job& jb = jobs_[job_];
+    const int B = spec_[jb.ai].B;
+    SharedMem* m = pick_smem(spec_[jb.ai].label);
+    const int k = (int)std::min<size_t>((size_t)m->opts.batchsize, h_idx_.size() - cursor_);
     const int32_t* idx = (const int32_t*)d_idx_ + cursor_;
     if (AnyP* s = key(m, "s")) {
       // extractGameState -> BoardFeature::extract (GameFeature.h:28-32): leaf planes, one row per state
@@ -450,11 +601,49 @@ class SelfPlayEngine : public elfhip_py::Engine {
       hk(hipMemcpy2D(s->row(0), (size_t)s->strides.at(0), d_cfeat_, feat_row_, feat_row_, k, hipMemcpyDeviceToHost), "copy s");
     }
     if (AnyP* g = m->get("game_idx"))
-      for (int i = 0; i < k; ++i) *(int32_t*)g->row(i) = h_idx_[cursor_ + i] / B_;
+      for (int i = 0; i < k; ++i) *(int32_t*)g->row(i) = h_idx_[cursor_ + i] / B;
     m->effective_batchsize = k;
     chunk_n_ = k;
     serving_ = m;
     return m;
+  }
+
+  // mode "play": the human's games go to Python as one "actor_white" batch of current-board planes
+  // (AIClientT(client_, {"actor_white"})->act(board_feature, &board_reply), ClientGameSelfPlay.cc:273-305)
+  SharedMem* serve_human() {
+    if (hcur_.empty()) {
+      for (int i = 0; i < n_; ++i) if (h_human_[i] && h_hmove_[i] < 0 && !h_force_end_[i] && !h_skip_[i]) hcur_.push_back(i);
+      if (hcur_.empty()) { phase_ = SELECT; h_skip_.assign(n_, 0); return nullptr_batch(); }
+      ck(elfhip_boards_features(boards_, d_bfeat_, ELFHIP_F32), "boards_features");
+      ck(elfhip_boards_legal_mask(boards_, (uint64_t*)d_mask_, nullptr), "legal_mask");
+      h_lmask_.resize((size_t)n_ * gi_.mask_words);
+      hk(hipMemcpy(h_lmask_.data(), d_mask_, h_lmask_.size() * 8, hipMemcpyDeviceToHost), "copy mask");
+    }
+    SharedMem* m = pick_smem("actor_white");
+    const int k = (int)std::min<size_t>((size_t)m->opts.batchsize, hcur_.size());
+    if (AnyP* s = key(m, "s"))
+      for (int i = 0; i < k; ++i)
+        hk(hipMemcpy(s->row(i), (const char*)d_bfeat_ + (size_t)hcur_[i] * feat_row_, feat_row_, hipMemcpyDeviceToHost), "copy s");
+    if (AnyP* g = m->get("game_idx")) for (int i = 0; i < k; ++i) *(int32_t*)g->row(i) = hcur_[i];
+    m->effective_batchsize = k;
+    chunk_n_ = k;
+    serving_ = m;
+    return m;
+  }
+  SharedMem* nullptr_batch() { return next_batch(); }
+  void human_reply(SharedMem* m, bool success) {
+    AnyP* a = key(m, "a");
+    const int k = chunk_n_;
+    for (int j = 0; j < k; ++j) {
+      const int i = hcur_[j];
+      const long long c = (success && a) ? *(const int64_t*)a->row(j) : -100;
+      if (c == -100) { h_skip_[i] = 1; continue; }            // nothing yet: the game sits this round out (:280-282)
+      if (c == -1) { h_force_end_[i] = 1; continue; }         // finish_game (:283-285)
+      if (c == -2) { h_force_end_[i] = 1; switch_sides_ = true; continue; }   // switch sides, finish_game (:286-292)
+      const bool legal = c >= 0 && c < gi_.num_actions && ((h_lmask_[(size_t)i * gi_.mask_words + c / 64] >> (c % 64)) & 1);
+      if (legal) h_hmove_[i] = (int16_t)c;                    // else "Invalid move ... please try again": asked again
+    }
+    hcur_.erase(hcur_.begin(), hcur_.begin() + k);
   }
 
   void refresh_states() {
@@ -471,11 +660,35 @@ class SelfPlayEngine : public elfhip_py::Engine {
     const size_t A = gi_.num_actions;
     const std::vector<int32_t> pre_ply = h_ply_;  // getPly() at the time of the move decides "diverse"
     hk(hipMemcpy(d_ply_, h_ply_.data(), (size_t)n_ * 4, hipMemcpyHostToDevice), "copy ply");
-    // chooseAction + mcts_make_diverse_move + getValue (ClientGameSelfPlay.cc:94-122)
-    ck(elfhip_mcts_pick_moves(mcts_, (const int32_t*)d_ply_, go_.policy_distri_cutoff, go_.seed, move_counter_++,
-                              (int16_t*)d_move_, (uint8_t*)d_pol_, (float*)d_val_), "mcts_pick_moves");
+    hk(hipMemset(d_move_, 0xFF, (size_t)n_ * 2), "memset");   // -1 = no move (a human who has not answered yet)
+    bool any_human = false;
+    for (int k = 0; k < n_ai_; ++k) {
+      std::vector<uint8_t> own(n_), po(n_);
+      bool any_po = false;
+      for (int i = 0; i < n_; ++i) {
+        own[i] = (!h_human_[i] && h_owner_[i] == k) ? 1 : 0;
+        po[i] = own[i] && h_ponly_[i];
+        any_po = any_po || po[i];
+        any_human = any_human || h_human_[i];
+      }
+      set_active(k, own);
+      // chooseAction + mcts_make_diverse_move + getValue (ClientGameSelfPlay.cc:94-122)
+      ck(elfhip_mcts_pick_moves(mcts_[k], (const int32_t*)d_ply_, go_.policy_distri_cutoff, go_.seed, move_counter_,
+                                (int16_t*)d_move_, (uint8_t*)d_pol_, (float*)d_val_), "mcts_pick_moves");
+      if (any_po) {  // actPolicyOnly: strongest prior, no diverse move, no policy record (:349-357)
+        hk(hipMemcpy(d_m8_, po.data(), (size_t)n_, hipMemcpyHostToDevice), "copy mask");
+        ck(elfhip_mcts_pick_policy_only(mcts_[k], (const uint8_t*)d_m8_, (int16_t*)d_move_, (float*)d_val_), "pick_policy_only");
+      }
+      ck(elfhip_mcts_set_active(mcts_[k], nullptr), "mcts_set_active");
+    }
+    ++move_counter_;
+    if (any_human) {  // the human's moves replace the (absent) AI moves of those games
+      hk(hipMemcpy(h_move_.data(), d_move_, (size_t)n_ * 2, hipMemcpyDeviceToHost), "copy");
+      for (int i = 0; i < n_; ++i) if (h_human_[i]) h_move_[i] = h_hmove_[i];
+      hk(hipMemcpy(d_move_, h_move_.data(), (size_t)n_ * 2, hipMemcpyHostToDevice), "copy");
+    }
     ck(elfhip_boards_step(boards_, (const int16_t*)d_move_, (uint8_t*)d_ok_), "boards_step");
-    ck(elfhip_mcts_advance(mcts_, (const int16_t*)d_move_), "mcts_advance");
+    for (int k = 0; k < n_ai_; ++k) ck(elfhip_mcts_advance(mcts_[k], (const int16_t*)d_move_), "mcts_advance");
     ck(elfhip_boards_legal_mask(boards_, (uint64_t*)d_mask_, (uint8_t*)d_term_), "legal_mask");
     ck(elfhip_boards_evaluate(boards_, (float*)d_reward_), "boards_evaluate");
     hk(hipMemcpy(h_move_.data(), d_move_, (size_t)n_ * 2, hipMemcpyDeviceToHost), "copy");
@@ -487,15 +700,17 @@ class SelfPlayEngine : public elfhip_py::Engine {
     refresh_states();  // ply and side to move AFTER the move (finished games still show their final state)
     int nfin = 0;
     for (int i = 0; i < n_; ++i) {
-      if (!h_ok_[i]) continue;  // "Something is wrong! Move cannot be applied": the reference logs and goes on
+      if (h_force_end_[i]) { h_term_[i] = 1; ++nfin; continue; }   // the human ended the game: finish_game without a move
+      if (h_move_[i] < 0 || !h_ok_[i]) { h_term_[i] = 0; continue; }  // no move this round / "Move cannot be applied": logged, goes on
       const bool diverse = pre_ply[i] <= go_.policy_distri_cutoff;
       cur_[i].moves.push_back(h_move_[i]);
-      cur_[i].values.push_back(h_val_[i]);
-      if (go_.policy_distri_training_for_all || diverse)
+      if (!h_human_[i]) cur_[i].values.push_back(h_val_[i]);       // mcts_update_info; a human move records no value
+      if (!h_human_[i] && !h_ponly_[i] && (go_.policy_distri_training_for_all || diverse))
         cur_[i].policies.emplace_back(h_pol_.begin() + (size_t)i * A, h_pol_.begin() + (size_t)(i + 1) * A);
       if (h_term_[i]) ++nfin;
     }
     if (nfin) {
+      hk(hipMemcpy(d_term_, h_term_.data(), (size_t)n_, hipMemcpyHostToDevice), "copy");
       for (int i = 0; i < n_; ++i) {
         if (!h_term_[i]) continue;
         // GameNotifier::OnGameEnd (DistriClient.h:285-298): MAX_STEP counts as "both lost"
@@ -513,33 +728,39 @@ class SelfPlayEngine : public elfhip_py::Engine {
           out_.push_back(m);
         }
       }
-      ck(elfhip_mcts_clear(mcts_, (const uint8_t*)d_term_), "mcts_clear");            // ai->endGame -> resetTree
-      ck(elfhip_boards_reset_mask(boards_, (const uint8_t*)d_term_), "boards_reset");  // GameStateExt::restart
+      for (int k = 0; k < n_ai_; ++k) ck(elfhip_mcts_clear(mcts_[k], (const uint8_t*)d_term_), "mcts_clear");  // ai->endGame -> resetTree
+      ck(elfhip_boards_reset_mask(boards_, (const uint8_t*)d_term_), "boards_reset");                     // GameStateExt::restart
       refresh_states();
     }
+    if (switch_sides_) { human_for_ = human_for_ == 0 ? 1 : 0; switch_sides_ = false; }
   }
 
   int game_;
   ContextOptions co_;
   GameOptions go_;
   elfhip_game_info gi_{};
-  int device_ = 0, n_ = 0, B_ = 1, R_ = 1, max_chunk_ = 1;
+  int device_ = 0, n_ = 0, max_chunk_ = 1, n_ai_ = 1, slotB_ = 0, human_for_ = 0;
   size_t feat_row_ = 0;
   elfhip_boards* boards_ = nullptr;
-  elfhip_mcts* mcts_ = nullptr;
+  elfhip_mcts* mcts_[2] = {nullptr, nullptr};
+  AiSpec spec_[2];
+  MsgRequest req_;
+  std::vector<Job> jobs_;
+  size_t job_ = 0;
   std::map<std::string, std::vector<SharedMem*>> by_label_;
   std::map<std::string, size_t> rr_;
   std::deque<SharedMem*> out_;
   std::vector<void*> allocs_;
   void *d_feat_ = nullptr, *d_need_ = nullptr, *d_pi_ = nullptr, *d_v_ = nullptr, *d_idx_ = nullptr, *d_cfeat_ = nullptr,
        *d_cpi_ = nullptr, *d_cv_ = nullptr, *d_move_ = nullptr, *d_pol_ = nullptr, *d_val_ = nullptr, *d_ply_ = nullptr,
-       *d_ok_ = nullptr, *d_term_ = nullptr, *d_mask_ = nullptr, *d_reward_ = nullptr;
-  std::vector<uint8_t> h_need_, h_pol_, h_ok_, h_term_;
-  std::vector<uint64_t> h_states_;
-  std::vector<int32_t> h_ply_, h_idx_, pend_[2];
-  std::vector<int> h_player_;
-  std::vector<int16_t> h_move_;
-  std::vector<float> h_val_, h_reward_, h_cv_, h_cpi_;
+       *d_ok_ = nullptr, *d_term_ = nullptr, *d_mask_ = nullptr, *d_reward_ = nullptr, *d_m8_ = nullptr, *d_nedges_ = nullptr,
+       *d_bfeat_ = nullptr;
+  std::vector<uint8_t> h_need_, h_pol_, h_ok_, h_term_, h_owner_, h_ponly_, h_human_, h_m8_, h_force_end_, h_skip_;
+  std::vector<uint64_t> h_states_, h_lmask_;
+  std::vector<int32_t> h_ply_, h_idx_, h_nedges_;
+  std::vector<int> h_player_, hcur_;
+  std::vector<int16_t> h_move_, h_hmove_;
+  std::vector<float> h_val_, h_reward_;
   std::vector<GameRecord> cur_;
   std::vector<long long> seq_;
   std::deque<GameRecord> records_;
@@ -548,12 +769,56 @@ class SelfPlayEngine : public elfhip_py::Engine {
   size_t cursor_ = 0;
   uint64_t move_counter_ = 0;
   SharedMem* serving_ = nullptr;
-  bool running_ = false, restart_pending_ = false;
+  bool running_ = false, restart_pending_ = false, waiting_ = false, switch_sides_ = false;
   DistriClient client_;
   std::vector<ClientGameSelfPlay> games_;
 };
 
-void DistriClient::setRequest(long long black, long long white, int) { eng->on_request(black, white); }
+void DistriClient::setRequest(long long black, long long white, int num_threads) {  // DistriClient.h:378-388
+  MsgRequest r;
+  r.black_ver = black; r.white_ver = white; r.mcts_opt = eng->request().mcts_opt; r.num_game_thread_used = num_threads;
+  r.client_type = eng->request().client_type; r.player_swap = false; r.async = false;
+  eng->on_request(r);
+}
+// MsgRequest::createFromJson (common/record.h:160-198): {"vers": {"black_ver", "white_ver", "mcts_opt": {...}},
+// "client_ctrl": {"client_type", "num_game_thread_used", "player_swap", "async"}}; absent mcts_opt fields keep
+// the current values.  Returns the RestartReply name.
+std::string DistriClient::onRequestJson(const std::string& js) {
+  py::dict j = py::module_::import("json").attr("loads")(js);
+  MsgRequest r = eng->request();
+  py::dict vers = j["vers"];
+  r.black_ver = py::cast<long long>(vers["black_ver"]);
+  r.white_ver = py::cast<long long>(vers["white_ver"]);
+  if (vers.contains("mcts_opt")) {
+    py::dict mo = vers["mcts_opt"];
+    TSOptions& t = r.mcts_opt;
+    auto geti = [&](const char* k, int& v) { if (mo.contains(k)) v = py::cast<int>(mo[k]); };
+    auto getb = [&](const char* k, bool& v) { if (mo.contains(k)) v = py::cast<bool>(mo[k]); };
+    auto getf = [&](const char* k, float& v) { if (mo.contains(k)) v = py::cast<float>(mo[k]); };
+    geti("max_num_moves", t.max_num_moves); geti("num_threads", t.num_threads);
+    geti("num_rollouts_per_thread", t.num_rollouts_per_thread); geti("num_rollouts_per_batch", t.num_rollouts_per_batch);
+    getb("verbose", t.verbose); getb("verbose_time", t.verbose_time); getb("persistent_tree", t.persistent_tree);
+    getf("root_epsilon", t.root_epsilon); getf("root_alpha", t.root_alpha); geti("virtual_loss", t.virtual_loss);
+    geti("seed", t.seed);
+    if (mo.contains("pick_method")) t.pick_method = py::cast<std::string>(mo["pick_method"]);
+    if (mo.contains("alg_opt")) {
+      py::dict ao = mo["alg_opt"];
+      if (ao.contains("use_prior")) t.alg_opt.use_prior = py::cast<bool>(ao["use_prior"]);
+      if (ao.contains("c_puct")) t.alg_opt.c_puct = py::cast<float>(ao["c_puct"]);
+      if (ao.contains("unexplored_q_zero")) t.alg_opt.unexplored_q_zero = py::cast<bool>(ao["unexplored_q_zero"]);
+      if (ao.contains("root_unexplored_q_zero")) t.alg_opt.root_unexplored_q_zero = py::cast<bool>(ao["root_unexplored_q_zero"]);
+    }
+  }
+  r.player_swap = false; r.async = false; r.client_type = 1; r.num_game_thread_used = -1;
+  if (j.contains("client_ctrl")) {
+    py::dict cc = j["client_ctrl"];
+    if (cc.contains("client_type")) r.client_type = py::cast<int>(cc["client_type"]);
+    if (cc.contains("num_game_thread_used")) r.num_game_thread_used = py::cast<int>(cc["num_game_thread_used"]);
+    if (cc.contains("player_swap")) r.player_swap = py::cast<bool>(cc["player_swap"]);
+    if (cc.contains("async")) r.async = py::cast<bool>(cc["async"]);
+  }
+  return eng->on_request(r);
+}
 int ClientGameSelfPlay::getCurrentPlayer() const { return eng->player_of(idx); }
 std::vector<int> ClientGameSelfPlay::getValidMoves() const { return eng->valid_moves_of(idx); }
 std::vector<uint64_t> ClientGameSelfPlay::getStateWords() const { return eng->state_of(idx); }
@@ -569,6 +834,7 @@ class GameContext {  // elfgames/<game>/train/GameContext.h:46-160
   py::list takeRecords() { return eng_->take_records(); }
   std::string dumpRecordsJson(bool clear) { return eng_->dump_records_json(clear); }
   py::dict searchStats() { return eng_->search_stats(); }
+  py::list aiInfo() { return eng_->ai_info(); }
 
  private:
   std::unique_ptr<SelfPlayEngine> eng_;
@@ -594,10 +860,13 @@ PYBIND11_MODULE(ELFGAME_MODULE, m) {
       // over ZMQ, DistriClient.h:104-122) and the search counters of elfhip_mcts_stats
       .def("takeRecords", &GameContext::takeRecords)
       .def("dumpRecordsJson", &GameContext::dumpRecordsJson, py::arg("clear") = true)
-      .def("searchStats", &GameContext::searchStats);
+      .def("searchStats", &GameContext::searchStats)
+      .def("aiInfo", &GameContext::aiInfo);
 
   py::class_<DistriClient>(m, "DistriClient", py::module_local())
       .def("setRequest", &DistriClient::setRequest, py::arg("black_ver"), py::arg("white_ver"), py::arg("numThreads") = -1)
+      // no binding in the reference: what its ZMQ dispatcher hands to ClientGameSelfPlay::OnReceive
+      .def("onRequestJson", &DistriClient::onRequestJson)
       .def("getGameStats", &DistriClient::getGameStats, ref)
       .def("getCheckersGameStats", &DistriClient::getGameStats, ref);  // russian_checkers' spelling (pybind/Pybind.cc:38-40)
 
