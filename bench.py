@@ -9,7 +9,9 @@ A "step" is ONE launch of the persistent playout kernel that advances every boar
 (boards stay resident in HBM; state lives in registers inside the launch).  Games shard across
 GPUs with no data-path collective (weak scaling: 65,536 boards per GPU).  Rank 0 prints one JSON
 line with the whole-job moves/s, the kernel's roofline record and a CPU baseline (the oracle timed
-on the host cores, N=1 only).
+on the host cores, N=1 only).  The same line carries, under "nn_rollouts", the other half of
+BASELINE.json's metric measured in the same run: NN-evaluated MCTS rollouts/s on configs[3]
+(4,096 Go games per GPU, 1,600 rollouts/move, 20x224 ResNet in bf16 MFMA) with its MFMA roofline.
 """
 import argparse
 import json
@@ -47,6 +49,78 @@ def cpu_baseline(threads=16, boards_per_thread=256, plies=8192):
                       % (threads, boards_per_thread, plies, dt)}
 
 
+def nn_rollouts_leg(games, steps, warmup, local, world, barrier):
+    """Second half of BASELINE.json's metric: NN-evaluated MCTS rollouts/s on configs[3] (Go 19x19 self-play,
+    4,096 games per GPU, 1,600 rollouts/move, 8 leaves per batch, virtual loss 1, 20-block x 224 ResNet in bf16
+    MFMA, seeded random weights).  One step = one search batch over all games: select (descents + Go moves +
+    18 planes) -> network forward on games*8 leaves -> backup.  Only leaves that went through the network count."""
+    import torch
+    import torch.distributed as dist
+    from elf_amd.boards import BoardBatch, GO19
+    from elf_amd.mcts import TreeSearchBatch
+    from elf_amd.net import PolicyValueNet, random_state_dict
+    n, B, R, blocks, dim = games, 8, 1600, 20, 224
+    bb = BoardBatch(GO19, n, device=local)
+    bb.playout(40, seed=SEED)                    # synthetic openings: 40 random-legal plies
+    bb.import_states(bb.export_states())         # clean game record for the planes / superko set
+    max_nodes = R + R // 2 + 64
+    ts = TreeSearchBatch(GO19, n, device=local, num_rollouts_per_thread=R, num_rollouts_per_batch=B, virtual_loss=1, c_puct=1.5,
+                         max_nodes=max_nodes, max_edges=max_nodes * 300)
+    cfg = dict(planes=18, board=19, dim=dim, num_block=blocks, num_action=362)
+    net = PolicyValueNet(max_batch=n * B, device=local, **cfg)
+    net.load_state_dict(random_state_dict(seed=0, **cfg))
+    assert ts.set_roots(bb).cpu().numpy().all()
+    feat = torch.empty((n * B, 18, 19, 19), dtype=torch.float32, device="cuda")
+    need = torch.empty((n, B), dtype=torch.uint8, device="cuda")
+    pi = torch.empty((n * B, 362), dtype=torch.float32, device="cuda")
+    v = torch.empty((n * B, 1), dtype=torch.float32, device="cuda")
+    L = ts.L
+
+    def step(ev=None):
+        if ev: ev[0].record()
+        L.elfhip_mcts_select(ts.h, None, feat.data_ptr(), need.data_ptr())
+        if ev: ev[1].record()
+        L.elfhip_net_forward(net.h, feat.data_ptr(), n * B, pi.data_ptr(), None, v.data_ptr())
+        if ev: ev[2].record()
+        L.elfhip_mcts_backup(ts.h, pi.data_ptr(), v.data_ptr())
+        if ev: ev[3].record()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    s0, _ = ts.stats()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(evs[k])
+    barrier()
+    dt = time.perf_counter() - t0
+    s1, flags = ts.stats()
+    evals = s1["evals"] - s0["evals"]
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([evals], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    sel = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
+    fwd = sum(e[1].elapsed_time(e[2]) for e in evs) / steps
+    bak = sum(e[2].elapsed_time(e[3]) for e in evs) / steps
+    macs = 361 * (9 * 18 * dim + blocks * 2 * 9 * dim * dim + 2 * dim) + 361 * 362 + 361 * 256 + 256   # SURVEY.md 8(d)
+    tf = 2.0 * macs * n * B / (fwd * 1e-3) / 1e12
+    return {"metric": "go_nn_evaluated_mcts_rollouts_per_sec", "value": int(tot.item()) / float(tmax.item()), "unit": "rollouts/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": float(tmax.item()) / steps * 1e3, "dtype": "bf16",
+            "data": "synthetic", "scaling": "weak",
+            "config": {"workload": "Go 19x19 self-play, %d games per GPU, %d rollouts/move, %d leaves/batch, vloss 1, %d-block x %d "
+                                   "ResNet bf16 (BASELINE.json configs[3]); one step = one search batch over all games"
+                                   % (n, R, B, blocks, dim)},
+            "time_split_ms": {"select_expand_planes": sel, "network": fwd, "backup": bak},
+            "parked_trees": int((flags != 0).sum().item()),
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None,
+                         "kernel": "conv3x3_board_kernel<224,19,1> (41 launches per forward)", "kernel_ms": fwd,
+                         "gflop_per_position": 2.0 * macs / 1e9, "positions_per_sec": n * B / (fwd * 1e-3)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,6 +129,9 @@ def main():
     ap.add_argument("--boards", type=int, default=BOARDS_PER_GPU)
     ap.add_argument("--plies", type=int, default=PLIES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-nn-rollouts", action="store_true", help="skip the configs[3] leg (NN-evaluated MCTS rollouts/s)")
+    ap.add_argument("--nn-games", type=int, default=4096)
+    ap.add_argument("--nn-steps", type=int, default=6)
     args = ap.parse_args()
 
     import torch
@@ -112,6 +189,14 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt_all, moves_all = float(tmax.item()), int(tot.item())
 
+    # free the playout slab before the self-play leg (it needs ~160 GB of tree arenas and activations)
+    del bb
+    nn = None
+    if not args.no_nn_rollouts:
+        try:
+            nn = nn_rollouts_leg(args.nn_games, args.nn_steps, 2, local, world, barrier)
+        except Exception as e:   # the headline line must not be lost to the secondary leg
+            nn = {"metric": "go_nn_evaluated_mcts_rollouts_per_sec", "value": None, "error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         moves_per_launch = moves / max(1, args.steps)
         achieved = ALGO_BYTES_PER_MOVE * moves_per_launch / (kern_ms * 1e-3) / 1e9
@@ -136,6 +221,8 @@ def main():
                          "kernel": "go_playout_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_move": ALGO_BYTES_PER_MOVE},
         }
+        if nn is not None:
+            out["nn_rollouts"] = nn
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

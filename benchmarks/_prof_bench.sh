@@ -7,8 +7,8 @@ ROOT=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- python3 $ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 2 > $OUT/fetch.log 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- python3 $ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 2 > $OUT/write.log 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT -o sq -- python3 $ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 2 > $OUT/sq.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python3 $ROOT/bench.py --no-cpu-baseline --no-nn-rollouts --steps 20 > $OUT/stats.log 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- python3 $ROOT/bench.py --no-cpu-baseline --no-nn-rollouts --steps 5 --warmup 2 > $OUT/fetch.log 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- python3 $ROOT/bench.py --no-cpu-baseline --no-nn-rollouts --steps 5 --warmup 2 > $OUT/write.log 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT -o sq -- python3 $ROOT/bench.py --no-cpu-baseline --no-nn-rollouts --steps 5 --warmup 2 > $OUT/sq.log 2>&1 || exit 1
 find $OUT -name "*.csv" | head -20

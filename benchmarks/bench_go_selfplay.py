@@ -34,7 +34,7 @@ def main():
     import torch
     from elf_amd.boards import BoardBatch, GO19
     from elf_amd.mcts import TreeSearchBatch
-    from elf_amd.net import PolicyValueNet
+    from elf_amd.net import PolicyValueNet, random_state_dict
     n, B = a.games, a.batch
     bb = BoardBatch(GO19, n)
     bb.playout(a.open_plies, seed=0x5EED0001)
@@ -46,8 +46,7 @@ def main():
                          max_nodes=max_nodes, max_edges=max_edges)
     cfg = dict(planes=18, board=19, dim=a.dim, num_block=a.blocks, num_action=362)
     net = PolicyValueNet(max_batch=n * B, **cfg)
-    from oracle.model_ref import seeded_model
-    net.load_state_dict(seeded_model(seed=0, **cfg).state_dict())
+    net.load_state_dict(random_state_dict(seed=0, **cfg))
     assert ts.set_roots(bb).cpu().numpy().all()
     feat = torch.empty((n * B, 18, 19, 19), dtype=torch.float32, device="cuda")
     need = torch.empty((n, B), dtype=torch.uint8, device="cuda")

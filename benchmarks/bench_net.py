@@ -24,12 +24,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     a = ap.parse_args()
     import torch
-    from elf_amd.net import PolicyValueNet
-    from oracle.model_ref import seeded_model
+    from elf_amd.net import PolicyValueNet, random_state_dict
     cfg = dict(planes=18, board=19, dim=224, num_block=20, num_action=362) if a.shape == "go" else \
         dict(planes=36, board=8, dim=128, num_block=10, num_action=170)
     net = PolicyValueNet(max_batch=a.batch, **cfg)
-    net.load_state_dict(seeded_model(seed=0, **cfg).state_dict())
+    net.load_state_dict(random_state_dict(seed=0, **cfg))
     x = (torch.rand((a.batch, cfg["planes"], cfg["board"], cfg["board"]), device="cuda") < 0.3).float()
     for _ in range(2):
         net.forward(x)

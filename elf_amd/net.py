@@ -39,6 +39,39 @@ def pack_state_dict(sd, num_block):
     return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
 
 
+def random_state_dict(planes, board, dim, num_block, num_action, seed=0, **_):
+    """Seeded random-init weights of the Model_PolicyValue architecture in the reference's state_dict layout
+    (benchmarks and smoke runs: there are no pretrained checkpoints offline).  torch's default initialisers:
+    kaiming-uniform(a=sqrt(5)) weights = U(+-1/sqrt(fan_in)), biases U(+-1/sqrt(fan_in)); BatchNorm weight 1,
+    bias 0, running stats (0, 1)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def uni(shape, fan_in):
+        b = 1.0 / float(fan_in) ** 0.5
+        return (torch.rand(shape, generator=g) * 2 - 1) * b
+
+    def conv(prefix, cout, cin, k):
+        sd[prefix + ".0.weight"] = uni((cout, cin, k, k), cin * k * k)
+        sd[prefix + ".0.bias"] = uni((cout,), cin * k * k)
+        sd[prefix + ".1.weight"] = torch.ones(cout)
+        sd[prefix + ".1.bias"] = torch.zeros(cout)
+        sd[prefix + ".1.running_mean"] = torch.zeros(cout)
+        sd[prefix + ".1.running_var"] = torch.ones(cout)
+
+    hw = board * board
+    conv("init_conv", dim, planes, 3)
+    for k in range(num_block):
+        conv("resnet.resnet.%d.conv_lower" % k, dim, dim, 3)
+        conv("resnet.resnet.%d.conv_upper" % k, dim, dim, 3)
+    conv("pi_final_conv", 1, dim, 1)
+    conv("value_final_conv", 1, dim, 1)
+    for name, o, i in (("pi_linear", num_action, hw), ("value_linear1", 256, hw), ("value_linear2", 1, 256)):
+        sd[name + ".weight"] = uni((o, i), i)
+        sd[name + ".bias"] = uni((o,), i)
+    return sd
+
+
 class PolicyValueNet:
     def __init__(self, planes=36, board=8, dim=128, num_block=10, num_action=170, bn_eps=1e-5, max_batch=4096, device=0, precision="bf16"):
         self.L = _lib.lib()
