@@ -181,7 +181,7 @@ __device__ inline void wait_vmcnt(int n) {
 template <int COUT, int H, int NBW>
 __global__ void __launch_bounds__(512)
 conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
-                     const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int B, int CIN, int relu) {
+                     const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int B, int CIN, int relu, int late_half) {
   constexpr int PW = H + 2, PP = PW * PW, HW = H * H;
   constexpr int PT = NBW * HW;             // output positions of this workgroup
   constexpr int NT = (PT + 15) / 16;       // position tiles
@@ -199,6 +199,7 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave & 1, wp = wave >> 1;
   const int r16 = lane & 15, q = lane >> 4;
+  const bool late = (wave >= 4) && late_half;
   // Persistent: this workgroup owns board groups blockIdx.x, blockIdx.x + gridDim.x, ... and runs ONE
   // continuous pipeline over all of them: the weight ring and the activation double buffer are indexed
   // by a stage / chunk counter that keeps counting across boards, so the first weight slices and the
@@ -325,12 +326,20 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
 #pragma unroll 1
     for (int s = 0; s < nstage; s += 2) {
       int inflight = 0;
-      if (issued < G + 6 && issued < total) { issue_next(); inflight += nA; }
-      if (issued < G + 6 && issued < total) { issue_next(); inflight += nA; }
-      if (tap == 3 || tap == 4) {
-        if (chunk + 1 < nchunk) { dma_x(g, (chunk + 1) * KC, (gchunk + 1) & 1); inflight += nX; }
-        else if (bi + 1 < nmine) { dma_x(g + (int)gridDim.x, 0, (gchunk + 1) & 1); inflight += nX; }
-      }
+      // The two waves that share a SIMD (w and w + 4) request their DMA pieces at opposite ends of the
+      // pair: after the barrier one of them issues loads while the other already feeds the matrix pipe,
+      // and before the next barrier the roles are swapped.  What is requested (decided from the state at
+      // the top of the pair) is the same for every wave.
+      const int G0 = G, tap0 = tap, chunk0 = chunk, gchunk0 = gchunk;
+      auto request = [&]() {
+        if (issued < G0 + 6 && issued < total) { issue_next(); inflight += nA; }
+        if (issued < G0 + 6 && issued < total) { issue_next(); inflight += nA; }
+        if (tap0 == 3 || tap0 == 4) {
+          if (chunk0 + 1 < nchunk) { dma_x(g, (chunk0 + 1) * KC, (gchunk0 + 1) & 1); inflight += nX; }
+          else if (bi + 1 < nmine) { dma_x(g + (int)gridDim.x, 0, (gchunk0 + 1) & 1); inflight += nX; }
+        }
+      };
+      if (!late) request();
       compute(tap, gslot, gchunk & 1);
       ++G; gslot = gslot + 1 == RING ? 0 : gslot + 1;
       if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
@@ -339,6 +348,7 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
         ++G; gslot = gslot + 1 == RING ? 0 : gslot + 1;
         if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
       }
+      if (late) request();
       wait_vmcnt(inflight);
       __builtin_amdgcn_s_barrier();
     }
@@ -618,6 +628,7 @@ struct NetImpl {
   float *fxin = nullptr, *fact[3] = {nullptr, nullptr, nullptr};
   bool loaded = false;
   bool use_board_kernel = true;   // ELFHIP_NET_TILE=positions selects the generic position-tiled kernel
+  int late_half = 1;              // waves 4-7 request their DMA pieces at the end of a stage pair (ELFHIP_NET_LATE=0: all at the top)
   int persist_wgs = 0;            // workgroups of the persistent board kernel (= CUs: the kernel's LDS allows one per CU); 0 = one per board group
   ~NetImpl() { for (void* p : allocs) (void)hipFree(p); }
 
@@ -753,7 +764,7 @@ struct NetImpl {
     const int ngroups = (B + NBW - 1) / NBW;
     const int grid = persist_wgs > 0 ? std::min(ngroups, persist_wgs) : ngroups;
     hipLaunchKernelGGL((conv3x3_board_kernel<COUT, H, NBW>), dim3(grid), dim3(512), smem, stream, x, c.w, c.b, res, out, B, c.cin,
-                       relu);
+                       relu, late_half);
   }
   template <int COUT>
   bool conv_board(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
@@ -870,6 +881,8 @@ int elfhip_net_create(const elfhip_net_config* cfg, int max_batch, int device, e
     n->persist_wgs = prop.multiProcessorCount;
     const char* e = getenv("ELFHIP_NET_PERSIST");   // 0 = one workgroup per board group (A/B timing only)
     if (e) n->persist_wgs = atoi(e);
+    e = getenv("ELFHIP_NET_LATE");
+    if (e) n->late_half = atoi(e);
   }
   int rc = n->alloc();
   if (rc != ELFHIP_OK) { delete n; return rc; }
