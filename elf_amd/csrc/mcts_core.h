@@ -28,13 +28,23 @@ struct Opt {
   int R, B, vl, use_prior; float c_puct; int uqz, ruqz, persistent, pick;
 };
 
+// Node and edge records are arrays of structures: a descent step reads ONE 32-byte node header and the
+// node's contiguous 24-byte edge records, and the backup writes back into the same lines.  (With one
+// array per field a node visit touched ~11 different cache lines and a rollout wrote ~50; the checkers
+// search moved 10x its algorithmic bytes through HBM, most of it partial-line write-backs.)
+constexpr int NODE_BYTES = 32;  // meta 0, ebase 4, visits 8, V 12, meanQ 16, parentQ 20, parent 24, paction 28
+constexpr int EDGE_BYTES = 24;  // prior 0, child 4, reward 8, visits 12, vloss 16, action 20
+template <class T, int STRIDE>
+struct Field {  // field of record i; indexes like the plain array it replaces
+  char* p;
+  __host__ __device__ inline T& operator[](int i) const { return *(T*)(p + (size_t)i * STRIDE); }
+};
+
 struct TreeDev {
   int n_trees, max_nodes, max_edges, state_words;  // state_words: u32 words of game state per node
-  // nodes [2][n_trees][max_nodes]
-  uint32_t* n_meta; uint32_t* n_ebase; int32_t* n_visits; float* n_V; float* n_meanQ; float* n_parentQ;
-  int32_t* n_parent; uint16_t* n_paction; uint32_t* n_state;
-  // edges [2][n_trees][max_edges]
-  uint16_t* e_action; float* e_prior; int32_t* e_child; float* e_reward; int32_t* e_visits; float* e_vloss;
+  char* n_rec;        // node headers [2][n_trees][max_nodes] x NODE_BYTES
+  uint32_t* n_state;  // game state per node [2][n_trees][max_nodes][state_words]
+  char* e_rec;        // edges [2][n_trees][max_edges] x EDGE_BYTES
   // per tree
   int32_t* t_arena; int32_t* t_nnodes; int32_t* t_nedges; int32_t* t_flags;
   // batch scratch
@@ -45,19 +55,22 @@ struct TreeDev {
 };
 
 struct TV {  // one tree, one arena
-  uint32_t* meta; uint32_t* ebase; int32_t* visits; float* V; float* meanQ; float* parentQ; int32_t* parent;
-  uint16_t* paction; uint32_t* state;
-  uint16_t* ea; float* ep; int32_t* ec; float* er; int32_t* ev; float* el;
+  Field<uint32_t, NODE_BYTES> meta, ebase; Field<int32_t, NODE_BYTES> visits; Field<float, NODE_BYTES> V, meanQ, parentQ;
+  Field<int32_t, NODE_BYTES> parent; Field<uint16_t, NODE_BYTES> paction;
+  uint32_t* state;
+  Field<uint16_t, EDGE_BYTES> ea; Field<float, EDGE_BYTES> ep; Field<int32_t, EDGE_BYTES> ec; Field<float, EDGE_BYTES> er;
+  Field<int32_t, EDGE_BYTES> ev; Field<float, EDGE_BYTES> el;
 };
 
 __device__ inline TV tree_view(const TreeDev& d, int t, int arena) {
   size_t nb = ((size_t)arena * d.n_trees + t) * d.max_nodes, eb = ((size_t)arena * d.n_trees + t) * d.max_edges;
   TV v;
-  v.meta = d.n_meta + nb; v.ebase = d.n_ebase + nb; v.visits = d.n_visits + nb; v.V = d.n_V + nb;
-  v.meanQ = d.n_meanQ + nb; v.parentQ = d.n_parentQ + nb; v.parent = d.n_parent + nb; v.paction = d.n_paction + nb;
+  char* nr = d.n_rec + nb * NODE_BYTES;
+  char* er = d.e_rec + eb * EDGE_BYTES;
+  v.meta.p = nr; v.ebase.p = nr + 4; v.visits.p = nr + 8; v.V.p = nr + 12;
+  v.meanQ.p = nr + 16; v.parentQ.p = nr + 20; v.parent.p = nr + 24; v.paction.p = nr + 28;
   v.state = d.n_state + nb * d.state_words;
-  v.ea = d.e_action + eb; v.ep = d.e_prior + eb; v.ec = d.e_child + eb; v.er = d.e_reward + eb;
-  v.ev = d.e_visits + eb; v.el = d.e_vloss + eb;
+  v.ep.p = er; v.ec.p = er + 4; v.er.p = er + 8; v.ev.p = er + 12; v.el.p = er + 16; v.ea.p = er + 20;
   return v;
 }
 
@@ -543,11 +556,8 @@ struct MctsBase {
     if (d.max_nodes > 30000) d.max_nodes = 30000;  // u16 node ids; the advance kernel maps them in LDS
     d.max_edges = opt->max_edges > 0 ? opt->max_edges : default_edges_per_node * d.max_nodes;
     const size_t NN = (size_t)2 * n_trees * d.max_nodes, NE = (size_t)2 * n_trees * d.max_edges, T = (size_t)n_trees;
-    MCTS_ALLOC(d.n_meta, NN * 4); MCTS_ALLOC(d.n_ebase, NN * 4); MCTS_ALLOC(d.n_visits, NN * 4); MCTS_ALLOC(d.n_V, NN * 4);
-    MCTS_ALLOC(d.n_meanQ, NN * 4); MCTS_ALLOC(d.n_parentQ, NN * 4); MCTS_ALLOC(d.n_parent, NN * 4);
-    MCTS_ALLOC(d.n_paction, NN * 2); MCTS_ALLOC(d.n_state, NN * 4 * (size_t)state_words);
-    MCTS_ALLOC(d.e_action, NE * 2); MCTS_ALLOC(d.e_prior, NE * 4); MCTS_ALLOC(d.e_child, NE * 4); MCTS_ALLOC(d.e_reward, NE * 4);
-    MCTS_ALLOC(d.e_visits, NE * 4); MCTS_ALLOC(d.e_vloss, NE * 4);
+    MCTS_ALLOC(d.n_rec, NN * NODE_BYTES); MCTS_ALLOC(d.n_state, NN * 4 * (size_t)state_words);
+    MCTS_ALLOC(d.e_rec, NE * EDGE_BYTES);
     MCTS_ALLOC(d.t_arena, T * 4); MCTS_ALLOC(d.t_nnodes, T * 4); MCTS_ALLOC(d.t_nedges, T * 4); MCTS_ALLOC(d.t_flags, T * 4);
     MCTS_ALLOC(d.traj_node, T * o.B * MAXD * 2); MCTS_ALLOC(d.traj_edge, T * o.B * MAXD * 2);
     MCTS_ALLOC(d.traj_len, T * o.B * 4); MCTS_ALLOC(d.leaf, T * o.B * 4); MCTS_ALLOC(d.locked, T * o.B);
