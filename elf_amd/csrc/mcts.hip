@@ -31,11 +31,15 @@ struct AmExtra {
 };
 
 __device__ inline uint64_t* node_board(const TV& tv, int node) { return (uint64_t*)(tv.state + (size_t)node * AM_SW); }
+// node states are 48-byte records in a 256-byte-aligned array: three 16-byte accesses
 __device__ inline void load_board(const uint64_t* p, Am& s) {
-  s.f[0] = p[0]; s.f[1] = p[1]; s.k[0] = p[2]; s.k[1] = p[3]; s.w4 = p[4]; s.w5 = p[5];
+  const ulonglong2* q = (const ulonglong2*)p;
+  const ulonglong2 a = q[0], b = q[1], c = q[2];
+  s.f[0] = a.x; s.f[1] = a.y; s.k[0] = b.x; s.k[1] = b.y; s.w4 = c.x; s.w5 = c.y;
 }
 __device__ inline void store_board(uint64_t* p, const Am& s) {
-  p[0] = s.f[0]; p[1] = s.f[1]; p[2] = s.k[0]; p[3] = s.k[1]; p[4] = s.w4; p[5] = s.w5;
+  ulonglong2* q = (ulonglong2*)p;
+  q[0] = make_ulonglong2(s.f[0], s.f[1]); q[1] = make_ulonglong2(s.k[0], s.k[1]); q[2] = make_ulonglong2(s.w4, s.w5);
 }
 
 struct AmGame {

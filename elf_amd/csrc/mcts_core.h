@@ -75,8 +75,10 @@ __device__ inline TV tree_view(const TreeDev& d, int t, int arena) {
 }
 
 __device__ inline void init_node(TV& tv, int id, float pq, int parent, int paction) {  // NodeT ctor tree_search_node.h:110-115
-  tv.meta[id] = NOT_VISITED; tv.ebase[id] = 0; tv.visits[id] = 0; tv.V[id] = 0.f;
-  tv.meanQ[id] = pq; tv.parentQ[id] = pq; tv.parent[id] = parent; tv.paction[id] = (uint16_t)paction;
+  // the 32-byte header as two 16-byte stores: {meta = NOT_VISITED, ebase 0, visits 0, V 0} {meanQ, parentQ, parent, paction}
+  char* r = tv.meta.p + (size_t)id * NODE_BYTES;
+  *(uint4*)r = make_uint4(NOT_VISITED, 0u, 0u, 0u);
+  *(uint4*)(r + 16) = make_uint4(__float_as_uint(pq), __float_as_uint(pq), (uint32_t)parent, (uint32_t)(uint16_t)paction);
 }
 
 // One descent from the root (single_rollout tree_search.h:319-378).  Wave-uniform; returns the leaf.
@@ -91,26 +93,31 @@ __device__ inline int select_one(const TreeDev& d, TV& tv, const Opt& o, int t, 
   uint16_t* te = d.traj_edge + ((size_t)t * o.B + slot) * MAXD;
   int node = 0, depth = 0;
   for (;;) {
-    const uint32_t meta = tv.meta[node];
+    // the whole 32-byte header in two 16-byte loads issued together: one memory round trip per level
+    const uint4 h0 = *(const uint4*)(tv.meta.p + (size_t)node * NODE_BYTES);        // meta, ebase, visits, V
+    const uint4 h1 = *(const uint4*)(tv.meta.p + (size_t)node * NODE_BYTES + 16);   // meanQ, parentQ, parent, paction
+    const uint32_t meta = h0.x;
     if ((meta & 0xFF) != VISITED) break;
     const int ne = (int)(meta >> 16);
     if (ne == 0) break;  // findMove: no edges (terminal position)
     if (depth >= MAXD) { flags |= FLAG_DEPTH_OVERFLOW; break; }
     const bool flip = (meta & META_FLIP) != 0;
-    const int eb = (int)tv.ebase[node];
-    float mq = tv.meanQ[node];
+    const int eb = (int)h0.y;
+    float mq = __uint_as_float(h1.x);
     if (o.uqz || (o.ruqz && depth == 0)) mq = 0.0f;
-    const float pq = tv.parentQ[node];
-    const int nv = tv.visits[node];
+    const float pq = __uint_as_float(h1.y);
+    const int nv = (int)h0.z;
     const double sq = sqrt((double)(nv + 1));
     float best = -INFINITY; int bestj = 0x7FFFFFFF, bestc = -1;
+    float bestvl = 0.f;   // the chosen edge's virtual loss, kept from the scan (no reload before the update)
     float total_uq = 0.f; int total_cnt = 0;
     for (int base = 0; base < ne; base += 64) {
       const int j = base + lane;
       const bool ok = j < ne;
-      float score = -INFINITY, uq = 0.f; int counted = 0, cj = -1;
+      float score = -INFINITY, uq = 0.f, vloss = 0.f; int counted = 0, cj = -1;
       if (ok) {  // EdgeInfo::getScore tree_search_base.h:175-201
-        const float prior = tv.ep[eb + j], reward = tv.er[eb + j], vloss = tv.el[eb + j];
+        const float prior = tv.ep[eb + j], reward = tv.er[eb + j];
+        vloss = tv.el[eb + j];
         const int visits = tv.ev[eb + j];
         cj = tv.ec[eb + j];  // fetched with the other edge fields: saves a dependent round trip after the argmax
         float r = flip ? -reward : reward;
@@ -132,15 +139,16 @@ __device__ inline int select_one(const TreeDev& d, TV& tv, const Opt& o, int t, 
           if ((cmask >> k) & 1) { total_uq += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uq), k)); total_cnt++; }
         }
         bestc = __builtin_amdgcn_readlane(cj, bestj == 0x7FFFFFFF ? 0 : bestj);
+        bestvl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vloss), bestj == 0x7FFFFFFF ? 0 : bestj));
       } else {
         // first strict maximum in edge order == max score, lowest index on ties
-        float s = score; int sj = ok ? j : 0x7FFFFFFF, sc = cj;
+        float s = score, sv = vloss; int sj = ok ? j : 0x7FFFFFFF, sc = cj;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-          float s2 = __shfl_xor(s, off); int j2 = __shfl_xor(sj, off), c2 = __shfl_xor(sc, off);
-          if (s2 > s || (s2 == s && j2 < sj)) { s = s2; sj = j2; sc = c2; }
+          float s2 = __shfl_xor(s, off), v2 = __shfl_xor(sv, off); int j2 = __shfl_xor(sj, off), c2 = __shfl_xor(sc, off);
+          if (s2 > s || (s2 == s && j2 < sj)) { s = s2; sj = j2; sc = c2; sv = v2; }
         }
-        if (s > best || (s == best && sj < bestj)) { best = s; bestj = sj; bestc = sc; }
+        if (s > best || (s == best && sj < bestj)) { best = s; bestj = sj; bestc = sc; bestvl = sv; }
         // total_unsigned_q is a float sum in edge order: keep the order (only counted edges add)
         unsigned long long cm = cmask;
         while (cm) {
@@ -153,7 +161,7 @@ __device__ inline int select_one(const TreeDev& d, TV& tv, const Opt& o, int t, 
     mq = (pq + total_uq) / (float)(total_cnt + 1);  // tree_search_node.h:240-241
     tv.meanQ[node] = mq;
     const int e = eb + bestj;
-    if (o.vl > 0) tv.el[e] = tv.el[e] + (float)o.vl;  // addVirtualLoss :246-264
+    if (o.vl > 0) tv.el[e] = bestvl + (float)o.vl;  // addVirtualLoss :246-264
     tn[depth] = (uint16_t)node; te[depth] = (uint16_t)bestj;
     int child = bestc;
     if (child < 0) {  // followEdge :295-317 + allocateState tree_search.h:209-224
@@ -233,16 +241,19 @@ __device__ inline void expand_edges(const TreeDev& d, TV& tv, int leaf, bool ter
     if (eb + m > d.max_edges) { flags |= FLAG_EDGE_OVERFLOW; m = 0; }
     for (int j = lane; j < m; j += 64) {
       const int p = S.pos[j];
-      tv.ea[eb + j] = S.keys[p]; tv.ep[eb + j] = S.pri[p];
-      tv.ec[eb + j] = -1; tv.er[eb + j] = 0.f; tv.ev[eb + j] = 0; tv.el[eb + j] = 0.f;
+      // one 24-byte edge record = three 8-byte stores: {prior, child -1} {reward 0, visits 0} {vloss 0, action}
+      uint2* rec = (uint2*)(tv.ep.p + (size_t)(eb + j) * EDGE_BYTES);
+      rec[0] = make_uint2(__float_as_uint(S.pri[p]), 0xFFFFFFFFu);
+      rec[1] = make_uint2(0u, 0u);
+      rec[2] = make_uint2(0u, (uint32_t)S.keys[p]);
     }
     __syncthreads();
     ne_cnt += m;
     edge_sum += (unsigned long long)m;
   }
-  tv.V[leaf] = value;
-  tv.ebase[leaf] = (uint32_t)eb;
-  tv.meta[leaf] = VISITED | (flip ? META_FLIP : 0u) | META_STATE_SET | ((uint32_t)m << 16);
+  // first half of the header in one store; a node that was never VISITED has no children, so numVisits is 0
+  *(uint4*)(tv.meta.p + (size_t)leaf * NODE_BYTES) =
+      make_uint4(VISITED | (flip ? META_FLIP : 0u) | META_STATE_SET | ((uint32_t)m << 16), (uint32_t)eb, 0u, __float_as_uint(value));
   __threadfence_block();
 }
 
@@ -265,8 +276,9 @@ __device__ inline void backup_batch(const TreeDev& d, TV& tv, const Opt& o, int 
       const int node = tn[i];
       const int e = (int)tv.ebase[node] + te[i];
       tv.visits[node] = tv.visits[node] + 1;
-      tv.er[e] = tv.er[e] + reward;
-      tv.ev[e] = tv.ev[e] + 1;
+      uint2* rv = (uint2*)(tv.er.p + (size_t)e * EDGE_BYTES);   // {reward, visits}: 8-byte aligned inside the record
+      const uint2 x = *rv;
+      *rv = make_uint2(__float_as_uint(__uint_as_float(x.x) + reward), x.y + 1u);
       tv.el[e] = tv.el[e] - (float)(o.vl * count);
     }
     __threadfence_block();
