@@ -40,6 +40,35 @@ def cpu(prefix, words, threads=16, boards=4096, plies=256):
             "sample": "%d threads x %d boards x %d plies (oracle), %.1f s" % (threads, boards, plies, dt)}
 
 
+def cpu_reference(threads=16, boards=256, plies=4096):
+    """The reference's own C++ (GameBoard.cc compiled unmodified into oracle/_ref/libref.so) driven through the
+    same playout: American checkers only (its GetValidMovesBinary formats a string and searches a std::map per
+    move, which is where its time goes).  None when oracle/_ref was not built."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from tests import _oracle
+    R, L = _oracle.ref(), _oracle.oracle()
+    if R is None or not hasattr(R, "ref_am_playout"):
+        return None
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    slabs = []
+    for t in range(threads):
+        s = np.zeros((boards, 6), dtype=np.uint64)
+        for b in range(boards):
+            L.am_clear(s[b])
+        slabs.append(s)
+
+    def run(i):
+        return R.ref_am_playout(slabs[i].reshape(-1), boards, i * boards, 0, plies, SEED)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        moves = sum(ex.map(run, range(threads)))
+    dt = time.perf_counter() - t0
+    return {"value": moves / dt, "unit": "moves/s", "cores": threads, "kind": "reference",
+            "sample": "%d threads x %d boards x %d plies through the compiled reference GameBoard.cc, %.1f s" % (threads, boards, plies, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--boards", type=int, default=65536)
@@ -76,6 +105,11 @@ def main():
                             "kernel": prefix + "playout_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_move": bytes_per_move}}
         if not a.no_cpu:
             out["cpu_baseline"] = cpu(prefix, words)
+            if name == "american":
+                ref = cpu_reference()
+                if ref is not None:
+                    out["cpu_baseline_port"] = out["cpu_baseline"]
+                    out["cpu_baseline"] = ref
         print(json.dumps(out), flush=True)
         bb.close()
 

@@ -112,4 +112,35 @@ void ref_am_action(int action, int64_t* move, int64_t* dir) {
   *dir = it->second[1];
 }
 
+
+// Random-legal playouts driven through the REFERENCE's own GetValidMovesBinary / CheckersPlay (same
+// counter-based RNG and reset rule as oracle/american.c am_playout and the GPU kernel): the reference
+// CPU path timed for benchmarks/bench_boards.py ("kind": "reference"), and a third cross-check of the
+// playout harness.  boards: n x 6 exported words, updated in place.  Returns moves played.
+static inline uint64_t ref_splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+uint64_t ref_am_playout(uint64_t* boards, int n, uint64_t board_id0, uint64_t step_base, int nply, uint64_t seed) {
+  uint64_t moves = 0;
+  for (int bi = 0; bi < n; ++bi) {
+    GameBoard b;
+    unpack(boards + (size_t)bi * 6, &b);
+    for (int t = 0; t < nply; ++t) {
+      auto m = GetValidMovesBinary(b);
+      int cnt = 0;
+      for (int i = 0; i < 170; ++i) cnt += m[i] != 0;
+      if (cnt == 0 || b._ply >= 250) { memset(&b, 0, sizeof(b)); ClearBoard(&b); continue; }
+      uint64_t r = ref_splitmix64(seed + (board_id0 + (uint64_t)bi) * 0x9E3779B97F4A7C15ull + step_base + (uint64_t)t);
+      int k = (int)(r % (uint64_t)cnt), a = 0;
+      for (a = 0; a < 170; ++a) if (m[a]) { if (k == 0) break; --k; }
+      CheckersPlay(&b, a);
+      ++moves;
+    }
+    pack(b, boards + (size_t)bi * 6);
+  }
+  return moves;
+}
 }  // extern "C"

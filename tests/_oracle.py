@@ -169,6 +169,9 @@ def ref():
         L.ref_am_is_over.restype = C.c_int
         L.ref_am_observation.argtypes = [_u64p, C.c_int, _i32p]
         L.ref_am_action.argtypes = [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        if hasattr(L, "ref_am_playout"):
+            L.ref_am_playout.argtypes = [_u64p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]
+            L.ref_am_playout.restype = C.c_uint64
         _ref = L
     return _ref
 

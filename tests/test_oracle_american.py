@@ -119,3 +119,23 @@ def test_live_against_compiled_reference():
             assert L.am_play(s, a) == R.ref_am_play(r, a)
             plies += 1
     assert plies > 5000
+
+
+def test_reference_driven_playouts_equal_oracle_playouts():
+    """ref_am_playout runs the random-legal playout through the compiled reference's own GetValidMovesBinary /
+    CheckersPlay (oracle/ref/ref_american.cc); the states after 300 plies (several finished games per board)
+    must equal the oracle's playout of the same boards.  It is also the `kind: "reference"` CPU baseline of
+    benchmarks/bench_boards.py."""
+    R = _oracle.ref()
+    if R is None or not hasattr(R, "ref_am_playout"):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    L = _oracle.oracle()
+    n = 64
+    a = np.zeros((n, 6), dtype=np.uint64)
+    for b in range(n):
+        L.am_clear(a[b])
+    r = a.copy()
+    ma = L.am_playout(a.reshape(-1), n, 7, 0, 300, 0x5EED0001)
+    mr = R.ref_am_playout(r.reshape(-1), n, 7, 0, 300, 0x5EED0001)
+    assert ma == mr and ma > 0
+    assert np.array_equal(a, r)
