@@ -1,0 +1,23 @@
+"""Segment timing of the board convolution (CONV_PROF build of net.hip only): cycles per wave spent in
+request / stage 1 / stage 2 / late request / vmcnt wait / barrier / epilogue, over one Go forward."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.getcwd())
+import torch
+from elf_amd.net import PolicyValueNet, random_state_dict
+from elf_amd import _lib
+L = _lib.lib()
+cfg = dict(planes=18, board=19, dim=224, num_block=20, num_action=362)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+net = PolicyValueNet(max_batch=B, **cfg)
+net.load_state_dict(random_state_dict(seed=0, **cfg))
+x = (torch.rand((B, 18, 19, 19), device="cuda") < 0.3).float()
+net.forward(x); torch.cuda.synchronize()
+out = (C.c_ulonglong * 64)()
+L.elfhip_debug_conv_prof(out, 1)
+net.forward(x); torch.cuda.synchronize()
+L.elfhip_debug_conv_prof(out, 0)
+names = ["request", "stage1", "stage2", "late_request", "vmcnt_wait", "barrier", "epilogue"]
+for w in range(8):
+    v = [out[w * 8 + k] for k in range(7)]
+    tot = sum(v)
+    print("wave %d total %.3e  " % (w, tot) + "  ".join("%s %.1f%%" % (n, 100.0 * a / tot) for n, a in zip(names, v)))

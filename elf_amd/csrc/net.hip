@@ -31,6 +31,14 @@ __device__ inline uint16_t f2bf(float f) {  // round to nearest even (inputs are
   return (uint16_t)(u >> 16);
 }
 __device__ inline float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+// two floats -> two bf16 in one word (lo, hi), round to nearest even: one v_cvt_pk_bf16_f32 on gfx950
+// (same results as f2bf for finite inputs; the board kernel's epilogue converts 168 values per lane)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ inline uint32_t pack_bf16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 
 constexpr int KC = 32;        // input channels per K step
 constexpr int LROW = 40;      // LDS row stride in bf16 (32 data + 8 pad = 80 B)
@@ -155,6 +163,40 @@ __device__ inline void wait_vmcnt(int n) {
   }
 }
 
+#ifdef CONV_PROF
+// timing-only instrumentation (never in the product build): cycles per segment of a stage pair, summed per wave
+__device__ unsigned long long g_conv_prof[8][8];
+__device__ inline unsigned long long conv_stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define CP_DECL unsigned long long cp_acc[7] = {0, 0, 0, 0, 0, 0, 0}, cp_t = conv_stamp()
+#define CP_SEG(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long _n = conv_stamp(); cp_acc[k] += _n - cp_t; cp_t = _n; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CP_FLUSH do { if (lane == 0) for (int k = 0; k < 7; ++k) atomicAdd(&g_conv_prof[wave][k], cp_acc[k]); } while (0)
+extern "C" int elfhip_debug_conv_prof(unsigned long long* h64, int reset) {
+  if (h64 && hipMemcpyFromSymbol(h64, HIP_SYMBOL(g_conv_prof), 512) != hipSuccess) return -2;
+  if (reset) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_prof), z, 512) != hipSuccess) return -2; }
+  return 0;
+}
+#else
+#define CP_DECL
+#define CP_SEG(k)
+#define CP_FLUSH
+#endif
+
+// One LDS-DMA wave-instruction (global_load_lds_dwordx4: lane l's 16 bytes at gsrc land at lds + 16*l), issued
+// from inline assembly.  With the compiler's own builtin every s_waitcnt for an LDS read in the same loop
+// degrades to lgkmcnt(0) - the builtin counts as a pending LDS access of a second kind - which drains the
+// activation fragment that was just requested for a LATER group of MFMAs in front of every group.  Issued
+// this way the fragment reads keep their counted waits (lgkmcnt(2), (1), ...).  The DMA's own completion is
+// tracked by hand in either form (wait_vmcnt + s_barrier before anything reads what it wrote).
+// M0 = LDS byte address of the destination; one wait state between the scalar write of M0 and its use.
+__device__ inline void lds_dma16(const char* gsrc, const char* lds_dst) {
+  const uint32_t l = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory", "m0");
+}
+
 // Board-tiled 3x3 convolution (the fast path for 19x19 and 8x8): one 512-thread workgroup owns NBW
 // whole boards.  For every 32-channel input chunk the padded activations of those boards are staged
 // in LDS ONCE and serve all nine taps, so HBM/L2 sees each activation once per layer instead of
@@ -181,7 +223,7 @@ __device__ inline void wait_vmcnt(int n) {
 template <int COUT, int H, int NBW>
 __global__ void __launch_bounds__(512)
 conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
-                     const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int B, int CIN, int relu, int late_half) {
+                     const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int B, int CIN, int relu, int late_half, int stagger) {
   constexpr int PW = H + 2, PP = PW * PW, HW = H * H;
   constexpr int PT = NBW * HW;             // output positions of this workgroup
   constexpr int NT = (PT + 15) / 16;       // position tiles
@@ -191,7 +233,7 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
   constexpr int XI = (XROWS * 5 + 63) / 64;   // 1-KiB DMA pieces per activation chunk (5 slots per row)
   constexpr int AI = COUT / 16;               // ... per weight slice
   constexpr int XBYTES = XI * 1024, ABYTES = AI * 1024;
-  constexpr int NXW = (XI + 7) / 8, NAW = (AI + 7) / 8;
+  constexpr int NXW = (XI + 7) / 8, NAW = AI <= 8 ? 1 : (AI + 3) / 4 - 1;   // weight pieces: see apiece()
   extern __shared__ __attribute__((aligned(1024))) char smemc[];
   constexpr int RING = 6;
   char* sA = smemc;                       // [RING][ABYTES]
@@ -208,6 +250,14 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
   const int ngroups = (B + NBW - 1) / NBW;
   const int nmine = ((int)blockIdx.x < ngroups) ? (ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   if (nmine == 0) return;
+  // Every workgroup does the same work, so left alone they all reach their epilogues (324 KB of residual
+  // reads and output stores per board) at the same moment and HBM sees 83-MB bursts between idle stretches.
+  // A one-time start offset of 0..3 quarter-boards per workgroup spreads those bursts over the board time.
+  if (stagger > 0 && nmine > 1) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    const unsigned long long wait = (unsigned long long)(((unsigned)blockIdx.x >> 3) & 3u) * (unsigned)stagger;
+    while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
 
   // per position tile of this lane: padded row, and the byte offset of its (dy,dx) = (-1,-1) neighbour
   int pb[NTW];
@@ -219,9 +269,14 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
     pb[nt] = (bl * PP + (y + 1) * PW + xw + 1 - (PW + 1)) * 80 + q * 16;
   }
   // DMA source offsets (bytes, relative to the group's first padded row / the weight slice)
+  // Which 1-KiB weight pieces (16 output channels each) a wave requests: the first eight go one to each wave,
+  // the rest to waves 0-3 only.  Those request at the top of a stage pair and then wait at the barrier for
+  // their partners (which request mid-pair, with the matrix pipe shared, and are the critical path): the
+  // extra pieces cost them slack, not time.
+  auto apiece = [&](int i) { return i == 0 ? wave : (wave < 4 ? 4 + 4 * i + wave : AI); };
   uint32_t aoff[NAW];
 #pragma unroll
-  for (int i = 0; i < NAW; ++i) aoff[i] = (uint32_t)(((wave + 8 * i) * 16 + r16) * CIN + q * 8) * 2u;
+  for (int i = 0; i < NAW; ++i) aoff[i] = (uint32_t)((apiece(i) * 16 + r16) * CIN + q * 8) * 2u;
 
   // activation chunk c0.. of board group g -> buffer buf.  LDS slot (16 B) k of the image holds channel
   // group k % 5 of padded row k / 5; slot 4 of a row is padding and re-fetches group 0, the tail of the
@@ -243,23 +298,24 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
       row = min(row, (uint32_t)(rows_left - 1));
       const uint32_t off = (row * CIN + (ch == 4 ? 0 : ch) * 8) * 2u;
       if (j < XI)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
-                                         (__attribute__((address_space(3))) void*)(sX + buf * XBYTES + j * 1024), 16, 0, 0);
+        lds_dma16(src + off, sX + buf * XBYTES + j * 1024);
     }
   };
   auto dma_a = [&](int tap, int c0, int buf) {
     const char* src = (const char*)(w + (size_t)tap * COUT * CIN + c0);
 #pragma unroll
     for (int i = 0; i < NAW; ++i) {
-      const int j = wave + 8 * i;
+      const int j = apiece(i);
       if (j < AI)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + aoff[i]),
-                                         (__attribute__((address_space(3))) void*)(sA + buf * ABYTES + j * 1024), 16, 0, 0);
+        lds_dma16(src + aoff[i], sA + buf * ABYTES + j * 1024);
     }
   };
 
   const int nchunk = CIN / KC, nstage = nchunk * 9;
-  const int nA = (AI - wave + 7) / 8, nX = (XI - wave + 7) / 8;   // pieces this wave issues per slice / chunk
+  int nA = 0;                                   // pieces this wave issues per weight slice / activation chunk
+#pragma unroll
+  for (int i = 0; i < NAW; ++i) nA += apiece(i) < AI ? 1 : 0;
+  const int nX = (XI - wave + 7) / 8;
   const int total = nmine * nstage;    // stages of all this workgroup's board groups
   // Weight slices are requested in global stage order; the slice of global stage t lives in ring slot
   // t % RING (tracked incrementally: it_* describe the next stage to request).
@@ -304,6 +360,7 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
     }
   };
 
+  CP_DECL;
   int G = 0;        // global stage index of the pair being computed
   int gslot = 0;    // G % RING
   int gchunk = 0;   // global chunk counter (activation buffer = gchunk & 1)
@@ -326,9 +383,11 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
 #pragma unroll 1
     for (int s = 0; s < nstage; s += 2) {
       int inflight = 0;
-      // The two waves that share a SIMD (w and w + 4) request their DMA pieces at opposite ends of the
-      // pair: after the barrier one of them issues loads while the other already feeds the matrix pipe,
-      // and before the next barrier the roles are swapped.  What is requested (decided from the state at
+      // The two waves that share a SIMD (w and w + 4) request their DMA pieces at different points of the
+      // pair: one right after the barrier, while the other already feeds the matrix pipe alone, the
+      // other between its two stages, when the first is in the middle of its MFMAs (in-kernel stamps:
+      // a wave spends ~700-850 cycles per pair issuing its ~5 DMA pieces; issued by both waves at the same
+      // point those cycles leave the matrix pipe idle).  What is requested (decided from the state at
       // the top of the pair) is the same for every wave.
       const int G0 = G, tap0 = tap, chunk0 = chunk, gchunk0 = gchunk;
       auto request = [&]() {
@@ -340,17 +399,23 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
         }
       };
       if (!late) request();
+      CP_SEG(0);
       compute(tap, gslot, gchunk & 1);
+      CP_SEG(1);
       ++G; gslot = gslot + 1 == RING ? 0 : gslot + 1;
       if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
+      if (late) request();   // between its two stages: the partner wave is in the middle of its MFMAs by now
+      CP_SEG(3);
       if (s + 1 < nstage) {
         compute(tap, gslot, gchunk & 1);
         ++G; gslot = gslot + 1 == RING ? 0 : gslot + 1;
         if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
       }
-      if (late) request();
+      CP_SEG(2);
       wait_vmcnt(inflight);
+      CP_SEG(4);
       __builtin_amdgcn_s_barrier();
+      CP_SEG(5);   // barrier wait
     }
     // epilogue: lane holds position r16 of each position tile, channels 4*q+reg of each channel tile.
     // Channel tile outermost so that the bias (one float4) and the NTW residual words of a tile are
@@ -403,8 +468,8 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
-        o[nt].x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        o[nt].y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        o[nt].x = pack_bf16(v[0], v[1]);
+        o[nt].y = pack_bf16(v[2], v[3]);
       }
       // Stores are issue-bound, so make them 16 bytes wide: lanes q and q+1 (16 lanes apart) hold
       // adjacent 4-channel groups.  v_permlane16_swap exchanges the odd 16-lane rows of one register
@@ -423,7 +488,9 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
         if (live[NTW - 1]) *(uint2*)(outg + obase[NTW - 1] + co) = o[NTW - 1];
       }
     }
+    CP_SEG(6);   // epilogue
   }
+  CP_FLUSH;
 }
 
 
@@ -628,6 +695,7 @@ struct NetImpl {
   float *fxin = nullptr, *fact[3] = {nullptr, nullptr, nullptr};
   bool loaded = false;
   bool use_board_kernel = true;   // ELFHIP_NET_TILE=positions selects the generic position-tiled kernel
+  int stagger = -1;               // start offset per workgroup phase in shader cycles; -1 = default_stagger(), 0 = off (ELFHIP_NET_STAGGER)
   int late_half = 1;              // waves 4-7 request their DMA pieces at the end of a stage pair (ELFHIP_NET_LATE=0: all at the top)
   int persist_wgs = 0;            // workgroups of the persistent board kernel (= CUs: the kernel's LDS allows one per CU); 0 = one per board group
   ~NetImpl() { for (void* p : allocs) (void)hipFree(p); }
@@ -753,6 +821,13 @@ struct NetImpl {
     hipLaunchKernelGGL(conv3x3_kernel<COUT>, dim3((M + BP - 1) / BP), dim3(256), 0, stream, x, c.w, c.b, res, out, B,
                        cfg.board, cfg.board, c.cin, relu);
   }
+  // start offset per phase = 1/8 of the estimated cycles per board group (stages x MFMAs of the two waves of a
+  // SIMD x 16 cycles x the measured ~2.1 ratio of loop time to matrix time): 22k cycles for the Go tower
+  template <int COUT, int H, int NBW>
+  static int default_stagger(int cin) {
+    constexpr int NT = (NBW * H * H + 15) / 16, NTW = (NT + 3) / 4, MTW = COUT / 32;
+    return (int)((cin / KC) * 9 * 2 * MTW * NTW * 16 * 2.1 / 8);
+  }
   template <int COUT, int H, int NBW>
   void launch_board(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
     constexpr size_t smem = (size_t)6 * (COUT / 16) * 1024 + (size_t)2 * ((NBW * (H + 2) * (H + 2) * 5 + 63) / 64) * 1024;
@@ -764,7 +839,7 @@ struct NetImpl {
     const int ngroups = (B + NBW - 1) / NBW;
     const int grid = persist_wgs > 0 ? std::min(ngroups, persist_wgs) : ngroups;
     hipLaunchKernelGGL((conv3x3_board_kernel<COUT, H, NBW>), dim3(grid), dim3(512), smem, stream, x, c.w, c.b, res, out, B, c.cin,
-                       relu, late_half);
+                       relu, late_half, stagger >= 0 ? stagger : default_stagger<COUT, H, NBW>(c.cin));
   }
   template <int COUT>
   bool conv_board(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
@@ -881,6 +956,8 @@ int elfhip_net_create(const elfhip_net_config* cfg, int max_batch, int device, e
     n->persist_wgs = prop.multiProcessorCount;
     const char* e = getenv("ELFHIP_NET_PERSIST");   // 0 = one workgroup per board group (A/B timing only)
     if (e) n->persist_wgs = atoi(e);
+    e = getenv("ELFHIP_NET_STAGGER");
+    if (e) n->stagger = atoi(e);
     e = getenv("ELFHIP_NET_LATE");
     if (e) n->late_half = atoi(e);
   }
