@@ -276,7 +276,7 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
   auto apiece = [&](int i) { return i == 0 ? wave : (wave < 4 ? 4 + 4 * i + wave : AI); };
   uint32_t aoff[NAW];
 #pragma unroll
-  for (int i = 0; i < NAW; ++i) aoff[i] = (uint32_t)((apiece(i) * 16 + r16) * CIN + q * 8) * 2u;
+  for (int i = 0; i < NAW; ++i) aoff[i] = (uint32_t)((apiece(i) * 16 + r16) * KC + q * 8) * 2u;   // piece = 1 KiB contiguous
 
   // activation chunk c0.. of board group g -> buffer buf.  LDS slot (16 B) k of the image holds channel
   // group k % 5 of padded row k / 5; slot 4 of a row is padding and re-fetches group 0, the tail of the
@@ -302,7 +302,9 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
     }
   };
   auto dma_a = [&](int tap, int c0, int buf) {
-    const char* src = (const char*)(w + (size_t)tap * COUT * CIN + c0);
+    // wb layout [tap][32-channel chunk][co][32]: the slice of one stage is COUT x 64 B contiguous, so a 1-KiB piece
+    // reads 8 full 128-B lines (with [tap][co][ci] it touched 16 half-used lines: twice the address work)
+    const char* src = (const char*)(w + ((size_t)tap * (CIN / KC) + c0 / KC) * COUT * KC);
 #pragma unroll
     for (int i = 0; i < NAW; ++i) {
       const int j = apiece(i);
@@ -677,7 +679,7 @@ net_heads_kernel(const T* __restrict__ x, int H, int W, int C, int A,
     allocs.push_back((void*)(ptr));                                                              \
   } while (0)
 
-struct ConvW { uint16_t* w = nullptr; float* b = nullptr; int cin = 0; };
+struct ConvW { uint16_t* w = nullptr; uint16_t* wb = nullptr; float* b = nullptr; int cin = 0; };  // w [tap][co][ci], wb [tap][ci/32][co][32]
 
 struct NetImpl {
   elfhip_net_config cfg{};
@@ -721,6 +723,7 @@ struct NetImpl {
     for (size_t i = 0; i < convs.size(); ++i) {
       convs[i].cin = i == 0 ? cin_pad : d;
       NALLOC(convs[i].w, (size_t)9 * d * convs[i].cin * 2);
+      NALLOC(convs[i].wb, (size_t)9 * d * convs[i].cin * 2);
       NALLOC(convs[i].b, (size_t)d * 4);
     }
     const size_t hw = (size_t)H * H;
@@ -791,6 +794,15 @@ struct NetImpl {
           for (int t = 0; t < 9; ++t) wq[((size_t)t * d + co) * cp + ci] = bf(wt[((size_t)co * cin + ci) * 9 + t] * sc);
       }
       HIPCHECK(hipMemcpy(convs[li].w, wq.data(), wq.size() * 2, hipMemcpyHostToDevice));
+      {  // the board kernel's copy: stage-major, one stage = COUT x 32 channels contiguous
+        std::vector<uint16_t> wb(wq.size());
+        const int nch = cp / KC;
+        for (int t = 0; t < 9; ++t)
+          for (int co = 0; co < d; ++co)
+            for (int ci = 0; ci < cp; ++ci)
+              wb[(((size_t)t * nch + ci / KC) * d + co) * KC + ci % KC] = wq[((size_t)t * d + co) * cp + ci];
+        HIPCHECK(hipMemcpy(convs[li].wb, wb.data(), wb.size() * 2, hipMemcpyHostToDevice));
+      }
       HIPCHECK(hipMemcpy(convs[li].b, bq.data(), bq.size() * 4, hipMemcpyHostToDevice));
     }
     auto head1x1 = [&](float* dw, float& db) -> int {
@@ -838,7 +850,7 @@ struct NetImpl {
     }
     const int ngroups = (B + NBW - 1) / NBW;
     const int grid = persist_wgs > 0 ? std::min(ngroups, persist_wgs) : ngroups;
-    hipLaunchKernelGGL((conv3x3_board_kernel<COUT, H, NBW>), dim3(grid), dim3(512), smem, stream, x, c.w, c.b, res, out, B, c.cin,
+    hipLaunchKernelGGL((conv3x3_board_kernel<COUT, H, NBW>), dim3(grid), dim3(512), smem, stream, x, c.wb, c.b, res, out, B, c.cin,
                        relu, late_half, stagger >= 0 ? stagger : default_stagger<COUT, H, NBW>(c.cin));
   }
   template <int COUT>
