@@ -223,7 +223,7 @@ __device__ inline void lds_dma16(const char* gsrc, const char* lds_dst) {
 template <int COUT, int H, int NBW>
 __global__ void __launch_bounds__(512)
 conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
-                     const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int B, int CIN, int relu, int late_half, int stagger) {
+                     const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int B, int CIN, int relu, int late_half, int stagger, int phases) {
   constexpr int PW = H + 2, PP = PW * PW, HW = H * H;
   constexpr int PT = NBW * HW;             // output positions of this workgroup
   constexpr int NT = (PT + 15) / 16;       // position tiles
@@ -255,7 +255,7 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
   // A one-time start offset of 0..3 quarter-boards per workgroup spreads those bursts over the board time.
   if (stagger > 0 && nmine > 1) {
     const unsigned long long t0 = __builtin_readcyclecounter();
-    const unsigned long long wait = (unsigned long long)(((unsigned)blockIdx.x >> 3) & 3u) * (unsigned)stagger;
+    const unsigned long long wait = (unsigned long long)(((unsigned)blockIdx.x >> 3) % (unsigned)phases) * (unsigned)stagger;
     while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
 
@@ -698,6 +698,7 @@ struct NetImpl {
   bool loaded = false;
   bool use_board_kernel = true;   // ELFHIP_NET_TILE=positions selects the generic position-tiled kernel
   int stagger = -1;               // start offset per workgroup phase in shader cycles; -1 = default_stagger(), 0 = off (ELFHIP_NET_STAGGER)
+  int stagger_phases = 4;         // number of distinct start offsets (ELFHIP_NET_STAGGER_PHASES)
   int late_half = 1;              // waves 4-7 request their DMA pieces at the end of a stage pair (ELFHIP_NET_LATE=0: all at the top)
   int persist_wgs = 0;            // workgroups of the persistent board kernel (= CUs: the kernel's LDS allows one per CU); 0 = one per board group
   ~NetImpl() { for (void* p : allocs) (void)hipFree(p); }
@@ -851,7 +852,7 @@ struct NetImpl {
     const int ngroups = (B + NBW - 1) / NBW;
     const int grid = persist_wgs > 0 ? std::min(ngroups, persist_wgs) : ngroups;
     hipLaunchKernelGGL((conv3x3_board_kernel<COUT, H, NBW>), dim3(grid), dim3(512), smem, stream, x, c.wb, c.b, res, out, B, c.cin,
-                       relu, late_half, stagger >= 0 ? stagger : default_stagger<COUT, H, NBW>(c.cin));
+                       relu, late_half, stagger >= 0 ? stagger : default_stagger<COUT, H, NBW>(c.cin), stagger_phases);
   }
   template <int COUT>
   bool conv_board(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
@@ -970,6 +971,8 @@ int elfhip_net_create(const elfhip_net_config* cfg, int max_batch, int device, e
     if (e) n->persist_wgs = atoi(e);
     e = getenv("ELFHIP_NET_STAGGER");
     if (e) n->stagger = atoi(e);
+    e = getenv("ELFHIP_NET_STAGGER_PHASES");
+    if (e && atoi(e) > 0) n->stagger_phases = atoi(e);
     e = getenv("ELFHIP_NET_LATE");
     if (e) n->late_half = atoi(e);
   }
