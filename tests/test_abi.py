@@ -38,3 +38,20 @@ def test_game_info_and_errors():
     assert L.elfhip_boards_create(_lib.AMERICAN, 0, 0, C.byref(h)) == -1
     assert L.elfhip_boards_reset(None) == -1
     assert L.elfhip_boards_count(None) == -1
+
+
+def test_random_state_dict_matches_the_documented_parameter_layout():
+    """elf_amd.net.random_state_dict (seeded weights for benchmarks) produces every tensor elfhip_net_load
+    expects, in shapes that flatten to elfhip_net_param_count (no GPU needed: counting only)."""
+    import ctypes as C
+    from elf_amd import _lib
+    from elf_amd.net import pack_state_dict, random_state_dict, state_dict_order
+    L = _lib.lib()
+    for cfg in (dict(planes=36, board=8, dim=32, num_block=2, num_action=170), dict(planes=18, board=19, dim=64, num_block=1, num_action=362)):
+        sd = random_state_dict(seed=3, **cfg)
+        assert set(sd) == set(state_dict_order(cfg["num_block"]))
+        blob = pack_state_dict(sd, cfg["num_block"])
+        c = _lib.NetConfig(cfg["planes"], cfg["board"], cfg["dim"], cfg["num_block"], cfg["num_action"], 1e-5)
+        assert blob.size == L.elfhip_net_param_count(C.byref(c))
+        sd2 = random_state_dict(seed=3, **cfg)
+        assert all((sd[k] == sd2[k]).all() for k in sd)      # seeded: reproducible
