@@ -165,3 +165,108 @@ def test_policy_only_for_black_matches_oracle():
     assert not (flags.cpu().numpy() & ~32).any()
     tot = {key: sum(o.stats()[key] for o in orc) for key in ("rollouts", "evals", "depth_sum", "edge_sum")}
     assert st["evals"] == tot["evals"] and st["edge_sum"] == tot["edge_sum"]
+
+
+def _two_ai_generic(game_id, n, nmoves, make_games, side_of, run_oracle, forward, export_ok, na, edge_cap):
+    """Two handles with different options over the same games, uniform evaluator; the handle that owns the side to
+    move searches (set_active), both advance.  Compared per move with two oracle searches per game."""
+    import torch
+    from elf_amd.mcts import TreeSearchBatch
+    o1 = dict(num_rollouts_per_thread=16, num_rollouts_per_batch=4, virtual_loss=1, c_puct=1.5)
+    o2 = dict(num_rollouts_per_thread=12, num_rollouts_per_batch=2, virtual_loss=1, c_puct=2.5)
+    games, bb, orc = make_games(o1, o2)
+    ts = [TreeSearchBatch(game_id, n, **o1), TreeSearchBatch(game_id, n, **o2)]
+    used = [0, 0]
+    for mv in range(nmoves):
+        pl = side_of(bb)
+        term = bb.terminated().cpu().numpy().astype(bool)
+        move = torch.full((n,), -1, dtype=torch.int16, device="cuda")
+        for k in (0, 1):
+            ts[k].set_active(torch.tensor(((pl == k) & ~term).astype(np.uint8), device="cuda"))
+            assert ts[k].set_roots(bb).cpu().numpy().all()
+            ts[k].run_uniform()
+            ts[k].L.elfhip_mcts_pick_moves(ts[k].h, None, 0, 0, 0, move.data_ptr(), None, None)
+        got = move.cpu().numpy()
+        for i in range(n):
+            if term[i]:
+                assert got[i] == -1
+                continue
+            k = int(pl[i])
+            r = run_oracle(orc[k][i], games, i)
+            used[k] += 1
+            assert got[i] == r["best"], (mv, i, k)
+            forward(games, i, r["best"])
+            for kk in (0, 1):
+                orc[kk][i].advance(r["best"])
+        bb.forward(move)
+        for k in (0, 1):
+            ts[k].treeAdvance(move)
+        assert export_ok(bb, games)
+    assert used[0] > 0 and used[1] > 0
+    for k in (0, 1):
+        st, flags = ts[k].stats()
+        assert not (flags.cpu().numpy() & ~32).any()
+        tot = {key: sum(o.stats()[key] for o in orc[k]) for key in ("rollouts", "evals", "depth_sum", "edge_sum")}
+        assert st == tot, (k, st, tot)
+
+
+@pytest.mark.parametrize("game", ["russian", "ugolki"])
+def test_two_ais_other_checkers_games(game):
+    import torch
+    from elf_amd.boards import BoardBatch
+    from tests._oracle import FlatGame
+    gid, n = dict(russian=1, ugolki=2)[game], 6
+    meta_word = 4 if game == "russian" else 3
+
+    def make(o1, o2):
+        games = [FlatGame(game) for _ in range(n)]
+        bb = BoardBatch(gid, n)
+        rng = np.random.default_rng(3)
+        for ply in range(4):
+            acts = np.full(n, -1, dtype=np.int16)
+            for i, g in enumerate(games):
+                if ply >= i % 5:
+                    continue
+                legal = g.legal()
+                acts[i] = legal[rng.integers(len(legal))]
+                assert g.forward(acts[i])
+            bb.forward(torch.tensor(acts, device="cuda"))
+        orc = [[OracleMcts(policy_kind=0, game=game, **_oopts(o)) for _ in range(n)] for o in (o1, o2)]
+        return games, bb, orc
+
+    _two_ai_generic(gid, n, 14, make,
+                    side_of=lambda bb: (bb.export_states()[:, meta_word] & np.uint64(1)).astype(np.uint8),
+                    run_oracle=lambda o, games, i: o.run(games[i]),
+                    forward=lambda games, i, a: games[i].forward(a),
+                    export_ok=lambda bb, games: np.array_equal(bb.export_states(), np.stack([g.board() for g in games])),
+                    na=None, edge_cap=128)
+
+
+def test_two_ais_go():
+    import torch
+    from elf_amd.boards import BoardBatch, GO19
+    from tests._oracle import GoBoards
+    n = 4
+
+    def make(o1, o2):
+        games = GoBoards(n)
+        bb = BoardBatch(GO19, n)
+        rng = np.random.default_rng(5)
+        for ply in range(6):
+            acts = np.full(n, -1, dtype=np.int16)
+            for i in range(n):
+                if ply >= (i * 3) % 7:
+                    continue
+                legal = [a for a in games.legal(i) if a != 361]
+                acts[i] = legal[rng.integers(len(legal))]
+                assert games.forward(acts[i], i)
+            bb.forward(torch.tensor(acts, device="cuda"))
+        orc = [[OracleMcts(policy_kind=0, game="go", **_oopts(o)) for _ in range(n)] for o in (o1, o2)]
+        return games, bb, orc
+
+    _two_ai_generic(GO19, n, 8, make,
+                    side_of=lambda bb: (bb.export_states()[:, 20] & np.uint64(1)).astype(np.uint8),
+                    run_oracle=lambda o, games, i: o.run(games.ptr(i)),
+                    forward=lambda games, i, a: games.forward(a, i),
+                    export_ok=lambda bb, games: np.array_equal(bb.export_states(), games.export_all()),
+                    na=None, edge_cap=362)
