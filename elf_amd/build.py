@@ -59,7 +59,9 @@ def build_cpp_tests(force=False, verbose=False):
 # Python-visible facade modules with the reference's module names (host C++ only, g++):
 # _elf and one _elfgames_<game> per game that has search kernels.
 PYB = os.path.join(HERE, "pybind")
-GAME_MODULES = {"_elfgames_american_checkers": 0, "_elfgames_russian_checkers": 1, "_elfgames_ugolki": 2}
+# _elfgames_go: the same GameContext surface over the build-defined Go 19x19 rules (the fork has no Go module;
+# the north star names the OpenGo configuration, BASELINE.json configs[0] / configs[3])
+GAME_MODULES = {"_elfgames_american_checkers": 0, "_elfgames_russian_checkers": 1, "_elfgames_ugolki": 2, "_elfgames_go": 3}
 
 
 def build_pybind(force=False, verbose=False):

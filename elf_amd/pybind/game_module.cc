@@ -183,7 +183,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
   ~SelfPlayEngine() override { release(); }
 
   std::map<std::string, int> getParams() const {  // common/GameFeature.h:225-232 (ugolki: unprefixed names, :215-222)
-    const std::string p = game_ == ELFHIP_UGOLKI ? "" : "checkers_";
+    const std::string p = (game_ == ELFHIP_UGOLKI || game_ == ELFHIP_GO19) ? "" : "checkers_";
     return {{p + "num_action", gi_.num_actions}, {p + "board_size", gi_.board_size},
             {p + "num_future_actions", 1}, {p + "num_planes", gi_.num_planes}};
   }
@@ -464,6 +464,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
   }
   bool two_models() { return !play_mode() && req_.white_ver >= 0 && label("actor_white"); }
   bool play_mode() const { return go_.mode == "play"; }
+  int ply_base() const { return game_ == ELFHIP_GO19 ? 1 : 0; }
 
  private:
   enum Phase { BEGIN, HUMAN, SELECT, SERVE, BACKUP, MOVE };
@@ -652,7 +653,8 @@ class SelfPlayEngine : public elfhip_py::Engine {
     for (int i = 0; i < n_; ++i) {
       const uint64_t w = h_states_[(size_t)i * gi_.state_words + mw.word];
       h_player_[i] = (int)(w & 1);
-      h_ply_[i] = (int32_t)((w >> mw.ply_shift) & ((1u << mw.ply_bits) - 1));
+      // getPly(): the checkers states count from 1 (GameBoard.cc ClearBoard), the Go slab stores moves played
+      h_ply_[i] = (int32_t)((w >> mw.ply_shift) & ((1u << mw.ply_bits) - 1)) + ply_base();
     }
   }
 
@@ -716,7 +718,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
         // GameNotifier::OnGameEnd (DistriClient.h:285-298): MAX_STEP counts as "both lost"
         WinRateStats& w = client_.stats.w;
         const float r = h_reward_[i];
-        if (h_ply_[i] >= gi_.max_ply) w.both_lost++; else if (r > 0) w.black_wins++; else w.white_wins++;
+        if (h_ply_[i] - ply_base() >= gi_.max_ply) w.both_lost++; else if (r > 0) w.black_wins++; else w.white_wins++;
         w.sum_reward += r; w.total_games++;
         cur_[i].game_idx = i; cur_[i].seq = seq_[i]++; cur_[i].reward = r;
         cur_[i].num_move = h_ply_[i] - 1; cur_[i].timestamp = (long long)std::time(nullptr);

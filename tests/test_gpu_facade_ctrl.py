@@ -226,3 +226,45 @@ def test_play_mode_human_through_actor_white():
     assert len(ends) >= n
     assert (GC.getGame(0).getStateWords()[4] >> 8) & 0xFFFF == 1   # restarted
     w.stop()
+
+
+def test_go_game_context_through_the_same_facade():
+    """_elfgames_go: the GameContext / Context.wait-step surface over the build-defined Go rules (BASELINE.json
+    configs[0] is Go self-play plumbing).  Two games, uniform actor, 16 rollouts per move: after ten moves the
+    boards equal the oracle's (Go rules + search restated in oracle/go.c / oracle/mcts.cpp; parity unpinned vs
+    ELF, which has no Go source in this fork)."""
+    import _elfgames_go as gomod
+    from tests._oracle import GoBoards
+    co = gomod.ContextOptions()
+    co.num_games, co.batchsize = 2, 8
+    m = co.mcts_options
+    m.num_threads, m.num_rollouts_per_thread, m.num_rollouts_per_batch, m.virtual_loss, m.alg_opt.c_puct = 1, 16, 4, 1, 1.5
+    go = gomod.GameOptions()
+    go.mode, go.policy_distri_cutoff = "selfplay", 0
+    GC = gomod.GameContext(co, go)
+    assert GC.getParams() == dict(num_action=362, board_size=19, num_future_actions=1, num_planes=18)
+    desc = dict(game_end=dict(batchsize=1), actor_black=dict(input=["s"], reply=["pi", "V", "a", "rv"], batchsize=8))
+    w = _gcwrapper.Wrapper(GC, 8, desc, num_recv=2)
+
+    def actor(batch, bs):
+        s = batch["s"]
+        assert s.shape == (bs, 18, 19, 19) and np.isin(s, (0.0, 1.0)).all()
+        assert (s[:, 16].reshape(bs, -1).max(1) + s[:, 17].reshape(bs, -1).max(1) == 1).all()   # exactly one side-to-move plane
+        return dict(pi=np.full((bs, 362), np.float32(1.0 / 362.0), dtype=np.float32), V=np.zeros(bs, dtype=np.float32),
+                    a=np.zeros(bs, dtype=np.int64), rv=np.zeros(bs, dtype=np.int64))
+    w.reg_callback("actor_black", actor)
+    w.start()
+    nmoves = 10
+    for _ in range(100000):
+        w.run()
+        if (GC.getGame(0).getStateWords()[20] >> 16) & 0xFFFF >= nmoves:
+            break
+    ply = (GC.getGame(0).getStateWords()[20] >> 16) & 0xFFFF
+    g = GoBoards(1)
+    om = OracleMcts(policy_kind=0, game="go", num_rollouts=16, rollouts_per_batch=4, virtual_loss=1, c_puct=1.5)
+    for _ in range(ply):
+        r = om.run(g.ptr(0))
+        assert g.forward(r["best"], 0)
+        om.advance(r["best"])
+    assert [int(x) for x in g.export(0)] == GC.getGame(0).getStateWords() == GC.getGame(1).getStateWords()
+    w.stop()
