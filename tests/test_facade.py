@@ -120,3 +120,18 @@ def test_russian_and_ugolki_modules_use_their_own_names():
     ctx = GC.ctx()
     sm = ctx.allocateSharedMem(ctx.createSharedMemOptions("actor_black", 4), ["s", "pi"])
     assert sm["s"].field().sz().vec() == [4, 16, 8, 8] and sm["pi"].field().sz().vec() == [4, 418]
+
+
+def test_go_module_surface():
+    """_elfgames_go: same classes over the Go build (18 planes, 19x19, 362 actions); shapes come from the C-ABI's
+    game table, no GPU needed."""
+    import _elfgames_go as gomod
+    co = gomod.ContextOptions(); co.num_games = 2
+    go = gomod.GameOptions(); go.mode = "selfplay"
+    GC = gomod.GameContext(co, go)
+    assert GC.getParams() == dict(num_action=362, board_size=19, num_future_actions=1, num_planes=18)
+    ctx = GC.ctx()
+    sm = ctx.allocateSharedMem(ctx.createSharedMemOptions("actor_black", 4), ["s", "pi", "V"])
+    assert sm["s"].field().sz().vec() == [4, 18, 19, 19] and sm["pi"].field().sz().vec() == [4, 362]
+    with pytest.raises(ValueError):       # json.JSONDecodeError from the request parser
+        gomod.GameContext(co, go).getClient().onRequestJson("{not json")
