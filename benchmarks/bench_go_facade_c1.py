@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[0] through the drop-in boundary: Go 19x19 self-play, 64 games, 64 rollouts/move, tiny
+2-block x 32 ResNet, driven the way the reference's selfplay.py drives it - `_elfgames_go.GameContext`, `ctx.wait()`
+-> Python actor callback (the model side; here elf_amd.net on the GPU, host tensors in and out like the reference's
+pinned batches) -> `ctx.step()`.  Reports NN-evaluated rollouts/s of the whole loop and where the wall time goes.
+    python benchmarks/bench_go_facade_c1.py [--games 64] [--rollouts 64] [--batchsize 512] [--moves 8]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "elf_amd", "pybind"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--games", type=int, default=64)
+    ap.add_argument("--rollouts", type=int, default=64)
+    ap.add_argument("--leaves", type=int, default=8)
+    ap.add_argument("--batchsize", type=int, default=512)
+    ap.add_argument("--moves", type=int, default=8)
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+    assert torch.cuda.is_available()
+    from elf_amd.net import PolicyValueNet, random_state_dict
+    from tests import _gcwrapper      # the 60-line GCWrapper stand-in (createSharedMemOptions / AnyP.set / wait / step)
+    import _elfgames_go as gomod
+    cfg = dict(planes=18, board=19, dim=32, num_block=2, num_action=362)
+    net = PolicyValueNet(max_batch=a.batchsize, **cfg)
+    net.load_state_dict(random_state_dict(seed=0, **cfg))
+    co = gomod.ContextOptions()
+    co.num_games, co.batchsize = a.games, a.batchsize
+    m = co.mcts_options
+    m.num_threads, m.num_rollouts_per_thread, m.num_rollouts_per_batch, m.virtual_loss, m.alg_opt.c_puct = 1, a.rollouts, a.leaves, 1, 1.5
+    go = gomod.GameOptions()
+    go.mode, go.policy_distri_cutoff = "selfplay", 0
+    GC = gomod.GameContext(co, go)
+    desc = dict(game_end=dict(batchsize=1), actor_black=dict(input=["s"], reply=["pi", "V", "a", "rv"], batchsize=a.batchsize))
+    w = _gcwrapper.Wrapper(GC, a.batchsize, desc, num_recv=2)
+    t_model = [0.0]
+    rows = [0]
+
+    def actor(batch, bs):
+        t0 = time.perf_counter()
+        out = net.forward(torch.from_numpy(batch["s"]).cuda())
+        pi, v = out["pi"].cpu().numpy(), out["V"].cpu().numpy().reshape(-1)
+        t_model[0] += time.perf_counter() - t0
+        rows[0] += bs
+        return dict(pi=pi, V=v, a=np.zeros(bs, dtype=np.int64), rv=np.zeros(bs, dtype=np.int64))
+
+    w.reg_callback("actor_black", actor)
+    w.start()
+
+    def ply():
+        return (GC.getGame(0).getStateWords()[20] >> 16) & 0xFFFF
+
+    while ply() < 2:            # warm-up: two moves
+        w.run()
+    rows[0] = 0; t_model[0] = 0.0
+    s0 = GC.searchStats()
+    p0 = ply()
+    t0 = time.perf_counter()
+    while ply() < p0 + a.moves:
+        w.run()
+    dt = time.perf_counter() - t0
+    s1 = GC.searchStats()
+    evals = s1["evals"] - s0["evals"]
+    print(json.dumps({"metric": "go_nn_evaluated_mcts_rollouts_per_sec", "value": evals / dt, "unit": "rollouts/s", "n_gpus": 1,
+                      "dtype": "bf16", "data": "synthetic",
+                      "config": {"workload": "Go 19x19 self-play through _elfgames_go GameContext wait/step, %d games, %d rollouts/move, "
+                                             "%d leaves/batch, 2-block x 32 ResNet as a Python actor (BASELINE.json configs[0])"
+                                             % (a.games, a.rollouts, a.leaves), "batchsize": a.batchsize, "moves_timed": a.moves},
+                      "rows_served": rows[0], "rollouts_all_per_sec": (s1["rollouts"] - s0["rollouts"]) / dt,
+                      "seconds": dt, "seconds_in_python_actor": t_model[0]}), flush=True)
+    w.stop()
+
+
+if __name__ == "__main__":
+    main()

@@ -184,6 +184,7 @@ __device__ inline int select_one(const TreeDev& d, TV& tv, const Opt& o, int t, 
 template <int NA, int MAXLEGAL>
 struct ExpandScratch {
   stdorder::Item items[NA + 2];
+  stdorder::Item sorted[NA];   // rank-sort output (distinct keys); with ties the serial emulation sorts items in place
   uint16_t keys[MAXLEGAL]; float pri[MAXLEGAL]; int16_t nxt[MAXLEGAL]; int16_t buckets[MAXLEGAL <= 64 ? 128 : 544];
   uint16_t pos[MAXLEGAL];
   int m;
@@ -207,22 +208,51 @@ __device__ inline void expand_edges(const TreeDev& d, TV& tv, int leaf, bool ter
       for (int i = lane; i < NA; i += 64) { S.items[i].key = 1.0f / (float)NA; S.items[i].idx = d.uniform_order[i]; }
     }
     __syncthreads();
-    if (pi && lane == 0) stdorder::sort_desc(S.items, NA);     // std::sort, MCTSGameActor.h:295-300
-    __syncthreads();
+    // std::sort descending by pi (MCTSGameActor.h:295-300).  With distinct keys the result is THE descending
+    // order whatever the algorithm, so the wave rank-sorts in parallel (rank = number of larger keys, every lane
+    // scans all NA keys as LDS broadcasts).  std::sort is not stable: only when two keys are equal (or a key is
+    // NaN) does the order depend on libstdc++'s introsort, and then lane 0 runs its exact emulation as before
+    // (a single lane's dependent LDS round trips made that ~0.5 ms per Go leaf).
+    const stdorder::Item* sorted = S.items;
+    if (pi) {
+      bool odd = false;
+      for (int c = 0; c < NA; c += 64) {
+        const int i = c + lane;
+        const bool in = i < NA;
+        const float ki = S.items[in ? i : 0].key;
+        int rank = 0, same = 0;
+        for (int j = 0; j < NA; ++j) {
+          const float kj = S.items[j].key;
+          rank += kj > ki ? 1 : 0;
+          same += kj == ki ? 1 : 0;
+        }
+        if (in) {
+          if (same != 1) odd = true;
+          else S.sorted[rank] = S.items[i];
+        }
+      }
+      if (__any(odd)) {
+        __syncthreads();
+        if (lane == 0) stdorder::sort_desc(S.items, NA);
+      } else {
+        sorted = S.sorted;
+      }
+      __syncthreads();
+    }
     // checkMove filter (:305-331): the legal items keep their sorted order.  Lanes test 64 items at a
     // time; an item's slot is the number of legal items before it (ballot + popcount).
     int kept = 0;
     for (int c = 0; c < NA; c += 64) {
       const int i = c + lane;
       const bool in = i < NA;
-      const int a = in ? (int)S.items[in ? i : 0].idx : 0;
+      const int a = in ? (int)sorted[in ? i : 0].idx : 0;
       uint64_t word = 0;
 #pragma unroll
       for (int q = 0; q < (NA + 63) / 64; ++q) word = (a >> 6) == q ? mk[q] : word;
       const bool legal = in && ((word >> (a & 63)) & 1);
       const unsigned long long b = __ballot(legal);
       const int pos = kept + __popcll(b & ((1ull << lane) - 1ull));
-      if (legal && pos < MAXLEGAL) { S.keys[pos] = (uint16_t)a; S.pri[pos] = S.items[i].key; }
+      if (legal && pos < MAXLEGAL) { S.keys[pos] = (uint16_t)a; S.pri[pos] = sorted[i].key; }
       kept += __popcll(b);
     }
     __syncthreads();
