@@ -134,6 +134,21 @@ ELF_HD void sort_desc(Item* a, int n) {
 // Iteration order of std::unordered_map<unsigned short, T> after inserting distinct keys[0..m)
 // in that order.  next: scratch int16[m]; buckets: scratch int16[bucket capacity >= 541].
 // out[0..m) receives POSITIONS (indices into keys) in iteration order.  m <= 512.
+// key % bucket_count for the bucket counts libstdc++'s prime rehash policy goes through below 542: constant
+// divisors compile to a multiply and a shift (the run-time modulo is ~40 instructions on the GPU)
+ELF_HD int mod_buckets(int x, int nb) {
+  switch (nb) {
+    case 1: return 0;
+    case 13: return x % 13;
+    case 29: return x % 29;
+    case 59: return x % 59;
+    case 127: return x % 127;
+    case 257: return x % 257;
+    case 541: return x % 541;
+    default: return x % nb;
+  }
+}
+
 ELF_HD void umap_iteration_order(const uint16_t* keys, int m, int16_t* next, int16_t* buckets, uint16_t* out) {
   const int16_t NONE = -1, BB = -2;  // BB = the list's before-begin sentinel
   int nb = 1, count = 0;
@@ -150,7 +165,7 @@ ELF_HD void umap_iteration_order(const uint16_t* keys, int m, int16_t* next, int
       int bbegin = 0;
       while (p != NONE) {
         int16_t nx = next[p];
-        int b = keys[p] % grow;
+        int b = mod_buckets(keys[p], grow);
         if (buckets[b] == NONE) {
           next[p] = head; head = p; buckets[b] = BB;
           if (next[p] != NONE) buckets[bbegin] = p;
@@ -165,14 +180,14 @@ ELF_HD void umap_iteration_order(const uint16_t* keys, int m, int16_t* next, int
       nb = grow;
     }
     // _M_insert_bucket_begin
-    int b = keys[i] % nb;
+    int b = mod_buckets(keys[i], nb);
     if (buckets[b] != NONE) {
       int16_t before = buckets[b];
       if (before == BB) { next[i] = head; head = (int16_t)i; }
       else { next[i] = next[before]; next[before] = (int16_t)i; }
     } else {
       next[i] = head; head = (int16_t)i;
-      if (next[i] != NONE) buckets[keys[next[i]] % nb] = (int16_t)i;
+      if (next[i] != NONE) buckets[mod_buckets(keys[next[i]], nb)] = (int16_t)i;
       buckets[b] = BB;
     }
     ++count;
