@@ -216,10 +216,14 @@ __device__ inline void go_place(GoS& s, bool act, uint32_t r, uint32_t bit, cons
   uint32_t ncap = 0, cap_pt = 0;
   PROF_T0;
   uint32_t F[GN];
+  // the stone as a one-hot row set, built once (one compare per row); the loops below shift it by a row or a
+  // column instead of comparing the row index again (one wave per SIMD: registers are not the constraint)
+  uint32_t ST[GN];
+  ROWS(i) ST[i] = (uint32_t)i == r ? bit : 0u;
   // ---- captures: opponent groups in atari next to the stone (their one liberty is this point) ----
   bool own_at_nbr = false;  // an own group in atari touches the point: it merges and must be rewritten
   ROWS(i) {
-    const uint32_t s0 = (uint32_t)i == r ? bit : 0u, su = (uint32_t)i + 1 == r ? bit : 0u, sd = (uint32_t)i == r + 1 ? bit : 0u;
+    const uint32_t s0 = ST[i], su = i + 1 < GN ? ST[i + 1 < GN ? i + 1 : 0] : 0u, sd = i > 0 ? ST[i > 0 ? i - 1 : 0] : 0u;
     const uint32_t nbr = ((s0 << 1) | (s0 >> 1) | su | sd) & FULL;
     F[i] = nbr & s.Q[i] & s.AT[i];
     own_at_nbr = own_at_nbr || (nbr & s.P[i] & s.AT[i]) != 0;
@@ -255,7 +259,7 @@ __device__ inline void go_place(GoS& s, bool act, uint32_t r, uint32_t bit, cons
   // ---- the stone itself ----
   uint32_t E[GN];
   ROWS(i) {
-    const uint32_t s0 = (uint32_t)i == r ? bit : 0u;
+    const uint32_t s0 = ST[i];
     s.P[i] |= s0;
     F[i] = s0;
     E[i] = ~(s.P[i] | s.Q[i]) & FULL;
@@ -270,9 +274,12 @@ __device__ inline void go_place(GoS& s, bool act, uint32_t r, uint32_t bit, cons
   //      a neighbour in atari was just captured. ----
 #pragma unroll 1
   for (int d = 0; d < 4; ++d) {  // 0 up, 1 down, 2 left, 3 right
-    const uint32_t rr = d == 0 ? r - 1u : d == 1 ? r + 1u : r;      // r - 1 wraps to a row that does not exist
-    const uint32_t bb = d == 2 ? (bit >> 1) : d == 3 ? ((bit << 1) & FULL) : bit;
-    ROWS(i) F[i] = ((uint32_t)i == rr ? bb : 0u) & s.Q[i];
+    // the neighbouring point in direction d: the stone's row set moved up / down a row or left / right a column
+    // (d is a scalar loop counter: four small copies of the seed loop behind scalar branches, one shared growth)
+    if (d == 0) { ROWS(i) F[i] = (i + 1 < GN ? ST[i + 1 < GN ? i + 1 : 0] : 0u) & s.Q[i]; }
+    else if (d == 1) { ROWS(i) F[i] = (i > 0 ? ST[i > 0 ? i - 1 : 0] : 0u) & s.Q[i]; }
+    else if (d == 2) { ROWS(i) F[i] = (ST[i] >> 1) & s.Q[i]; }
+    else { ROWS(i) F[i] = (ST[i] << 1) & s.Q[i]; }   // Q has no bits above column 18
     const bool any = go_any_rows(F);
     PROF_ADD(0);
     if (!any) continue;
