@@ -48,6 +48,19 @@ void elfhip_set_error(const char* fmt, ...) {
 }
 
 
+// one wave running stdorder::umap_iteration_order_wave on m keys (the test hook below)
+static __global__ void __launch_bounds__(64) umap_order_wave_test_kernel(const uint16_t* keys, int m, uint16_t* iter_keys) {
+  __shared__ uint16_t k[512], seq[512], pos[512];
+  __shared__ __attribute__((aligned(16))) int rkey[512];
+  __shared__ int table[544];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < m; i += 64) k[i] = keys[i];
+  __syncthreads();
+  stdorder::umap_iteration_order_wave(k, m, lane, seq, rkey, table, pos);
+  __syncthreads();
+  for (int i = lane; i < m; i += 64) iter_keys[i] = k[pos[i]];
+}
+
 extern "C" {
 
 const char* elfhip_last_error(void) { return g_err; }
@@ -207,6 +220,23 @@ int elfhip_test_umap_order(int m, const uint16_t* h_keys, uint16_t* h_iter_keys)
   std::vector<uint16_t> pos((size_t)m + 1);
   stdorder::umap_iteration_order(h_keys, m, next.data(), buckets.data(), pos.data());
   for (int i = 0; i < m; ++i) h_iter_keys[i] = h_keys[pos[i]];
+  return ELFHIP_OK;
+}
+
+int elfhip_test_umap_order_wave(int m, const uint16_t* h_keys, uint16_t* h_iter_keys, int device) {
+  if (m < 0 || m > 512 || !h_keys || !h_iter_keys) { elfhip_set_error("test_umap_order_wave: bad arguments"); return ELFHIP_EINVAL; }
+  if (m == 0) return ELFHIP_OK;
+  HIPCHECK(hipSetDevice(device));
+  uint16_t* d = nullptr;
+  HIPCHECK(hipMalloc(&d, 2 * 512 * sizeof(uint16_t)));
+  hipError_t e = hipMemcpy(d, h_keys, (size_t)m * sizeof(uint16_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    umap_order_wave_test_kernel<<<1, 64>>>(d, m, d + 512);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(h_iter_keys, d + 512, (size_t)m * sizeof(uint16_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIPCHECK(e);
   return ELFHIP_OK;
 }
 

@@ -185,9 +185,11 @@ template <int NA, int MAXLEGAL>
 struct ExpandScratch {
   stdorder::Item items[NA + 2];
   stdorder::Item sorted[NA];   // rank-sort output (distinct keys); with ties the serial emulation sorts items in place
-  uint16_t keys[MAXLEGAL]; float pri[MAXLEGAL]; int16_t nxt[MAXLEGAL]; int16_t buckets[MAXLEGAL <= 64 ? 128 : 544];
-  uint16_t pos[MAXLEGAL];
-  int m;
+  uint16_t keys[MAXLEGAL]; float pri[MAXLEGAL];
+  // scratch of stdorder::umap_iteration_order_wave
+  __attribute__((aligned(16))) int rkey[(MAXLEGAL + 3) & ~3];
+  int table[MAXLEGAL <= 59 ? 64 : MAXLEGAL <= 127 ? 128 : 544];
+  uint16_t seq[MAXLEGAL]; uint16_t pos[MAXLEGAL];
 };
 
 // setEvaluation (tree_search_node.h:188-215) of a locked leaf from the actor's response
@@ -256,17 +258,17 @@ __device__ inline void expand_edges(const TreeDev& d, TV& tv, int leaf, bool ter
       kept += __popcll(b);
     }
     __syncthreads();
-    if (lane == 0) {
-      const bool over = kept > MAXLEGAL;
-      const int mm = over ? MAXLEGAL : kept;
-      float tot = 1e-10f;                                     // normalize :240-251
-      for (int k = 0; k < mm; ++k) tot += S.pri[k];
-      for (int k = 0; k < mm; ++k) S.pri[k] /= tot;
-      stdorder::umap_iteration_order(S.keys, mm, S.nxt, S.buckets, S.pos);
-      S.m = over ? -1 : mm;
-    }
+    // normalize (:240-251): the sum in the reference's order (every lane adds the same LDS broadcasts), the
+    // divisions one element per lane; then the hashtable order, a wave-parallel pass per bucket count
+    const bool over = kept > MAXLEGAL;
+    const int mm = over ? MAXLEGAL : kept;
+    float tot = 1e-10f;
+    for (int k = 0; k < mm; ++k) tot += S.pri[k];
     __syncthreads();
-    m = S.m;
+    for (int k = lane; k < mm; k += 64) S.pri[k] /= tot;
+    stdorder::umap_iteration_order_wave(S.keys, mm, lane, S.seq, S.rkey, S.table, S.pos);
+    __syncthreads();
+    m = over ? -1 : mm;
     if (m < 0) { flags |= FLAG_LEGAL_OVERFLOW; m = 0; }
     if (eb + m > d.max_edges) { flags |= FLAG_EDGE_OVERFLOW; m = 0; }
     for (int j = lane; j < m; j += 64) {

@@ -8,7 +8,8 @@
 //     13 -> 29 -> 59 -> 127 -> 257 -> 541, insert-at-bucket-begin, rehash relinking in list
 //     order) - NodeT::stateActions_ (tree_search_node.h:325) is walked in that order by UCT
 //     (:394) and MCTSResultT::addActions (tree_search_base.h:321), first strict maximum wins.
-// Checked against the real library by tests/test_stdorder.py through the elfhip_test_* hooks.
+// Checked against the real library by tests/test_stdorder.py through the elfhip_test_* hooks (the wave-parallel
+// form of the second one by tests/test_gpu_stdorder.py).
 #pragma once
 #include <stdint.h>
 #ifndef ELF_HD
@@ -195,5 +196,65 @@ ELF_HD void umap_iteration_order(const uint16_t* keys, int m, int16_t* next, int
   int k = 0;
   for (int16_t p = head; p != NONE; p = next[p]) out[k++] = (uint16_t)p;
 }
+
+#ifdef __HIPCC__
+// The same iteration order computed by one 64-lane wave instead of a walk of the linked list.  Between two
+// rehashes the container only ever (a) puts a node whose bucket is empty at the front of the whole list and
+// (b) puts a node whose bucket is occupied at the front of that bucket's run, and _M_rehash_aux applies exactly
+// those two rules to the old list in its order.  So with S = (list order at the last rehash) ++ (keys inserted
+// since), the list is S sorted by (index in S of the first element of the same bucket, descending; own index in
+// S, descending) - a rank every lane can count for its elements.  One such pass per bucket count 13 .. 541.
+// keys[0..m), m <= 512, all arrays in LDS: seq uint16[m], rkey int[(m+3)&~3] (16-byte aligned), table int[>= bucket
+// count].  out[0..m) receives positions as above.  Every lane of the wave must call it.
+template <int NB>
+__device__ inline void umap_epoch_wave(const uint16_t* keys, int cnt, int end, int lane, const uint16_t* src, uint16_t* dst,
+                                       int* rkey, int* table) {
+  for (int b = lane; b < NB; b += 64) table[b] = 0x7fffffff;
+  __syncthreads();
+  for (int i = lane; i < end; i += 64) {
+    const int p = i < cnt ? (int)src[i] : i;
+    atomicMin(&table[(int)keys[p] % NB], i);
+  }
+  __syncthreads();
+  const int end4 = (end + 3) & ~3;
+  for (int i = lane; i < end4; i += 64) {
+    const int p = i < cnt ? (int)src[i] : i;
+    rkey[i] = i < end ? table[(int)keys[p] % NB] * 1024 + i : (int)0x80000000;
+  }
+  __syncthreads();
+  for (int c = 0; c < end; c += 64) {
+    const int i = c + lane;
+    const bool in = i < end;
+    const int mine = rkey[in ? i : 0];
+    int before = 0;
+    for (int e = 0; e < end4; e += 4) {
+      const int4 k = *(const int4*)(rkey + e);   // the same address in every lane: an LDS broadcast
+      before += (k.x > mine ? 1 : 0) + (k.y > mine ? 1 : 0) + (k.z > mine ? 1 : 0) + (k.w > mine ? 1 : 0);
+    }
+    if (in) dst[before] = (uint16_t)(i < cnt ? (int)src[i] : i);
+  }
+  __syncthreads();
+}
+
+__device__ inline void umap_iteration_order_wave(const uint16_t* keys, int m, int lane, uint16_t* seq, int* rkey, int* table,
+                                                 uint16_t* out) {
+  if (m <= 0) return;
+  const int passes = 1 + (m > 13) + (m > 29) + (m > 59) + (m > 127) + (m > 257);
+  uint16_t* dst = (passes & 1) ? out : seq;   // ping-pong so that the last pass writes out
+  uint16_t* src = (passes & 1) ? seq : out;
+#define ELF_UMAP_PASS(CNT, NB, NEXT)                                                   \
+  if (m > CNT) {                                                                       \
+    umap_epoch_wave<NB>(keys, CNT, m < NEXT ? m : NEXT, lane, src, dst, rkey, table);  \
+    uint16_t* t = src; src = dst; dst = t;                                             \
+  }
+  ELF_UMAP_PASS(0, 13, 13)
+  ELF_UMAP_PASS(13, 29, 29)
+  ELF_UMAP_PASS(29, 59, 59)
+  ELF_UMAP_PASS(59, 127, 127)
+  ELF_UMAP_PASS(127, 257, 257)
+  ELF_UMAP_PASS(257, 541, 512)
+#undef ELF_UMAP_PASS
+}
+#endif
 
 }  // namespace stdorder

@@ -280,6 +280,8 @@ int elfhip_scatter_rows(const void* d_src, long long row_bytes, const int32_t* d
  * ---------------------------------------------------------------------------------------------- */
 int elfhip_test_sort_order(int n, const float* h_keys, uint16_t* h_order);
 int elfhip_test_umap_order(int m, const uint16_t* h_keys, uint16_t* h_iter_keys);
+/* the same order computed on `device` by the wave-parallel form the search kernels use (needs a GPU) */
+int elfhip_test_umap_order_wave(int m, const uint16_t* h_keys, uint16_t* h_iter_keys, int device);
 
 #ifdef __cplusplus
 }
