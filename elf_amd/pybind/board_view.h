@@ -1,0 +1,82 @@
+// Host-side views of one exported board state (the state words of include/elfhip.h) in the forms the
+// reference's console / web front-ends read through ClientGameSelfPlay:
+//   getBoard()  - american_checkers GameState.h:86-88 -> GetTrueState = GetObservation(board, BLACK) (GameBoard.cc:210-281)
+//                 russian_checkers CheckersState.h:81-83 -> GetTrueObservation (CheckersBoard.cc:139-148)
+//                 ugolki GameState.h:80-82 -> GetTrueObservation (GameBoard.cc:229-273)
+//   showBoard() - the " (NN)M" grid of GetTrueStateStr / GetTrueObservationStr (GameBoard.cc:284-311,
+//                 CheckersBoard.cc:151-170, ugolki GameBoard.cc:276-297) followed by the current player and
+//                 move number lines of GameState::showBoard (GameState.cc:32-60).  The reference prints the
+//                 last move through its m_to_h name table; that table is not built, the action index is printed.
+// Go has no counterpart in this fork (no Go sources): the same two views over the 19x19 stones.
+#pragma once
+#include <stdint.h>
+#include <iomanip>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace elfhip_view {
+
+// rows x cols grid, row-major.  Checkers family: black pieces positive as in the reference's observation for
+// BLACK_PLAYER (american / ugolki) or board.board itself (russian: white +1/+3, black -1/-3).  Go: black 1, white -1.
+inline std::vector<std::vector<int>> board_grid(int game, const uint64_t* w) {
+  const int n = game == 3 ? 19 : 8;
+  std::vector<std::vector<int>> g((size_t)n, std::vector<int>((size_t)n, 0));
+  if (game == 0) {  // w[0..1] forward[BLACK,WHITE], w[2..3] backward[BLACK,WHITE]; squares 0..34 without 8,17,26
+    const uint64_t black_pawn = w[0], white_king = w[1], black_king = w[2], white_pawn = w[3];
+    for (int i = 0; i < 35; ++i) {
+      int v = 0;
+      if ((black_king >> i) & 1) v = 3;
+      else if ((white_king >> i) & 1) v = -3;
+      else if ((black_pawn >> i) & 1) v = 1;
+      else if ((white_pawn >> i) & 1) v = -1;
+      if (!v) continue;
+      const int sq = i - i / 9;
+      g[(size_t)(7 - sq / 4)][(size_t)(6 - sq % 4 * 2 + (sq / 4) % 2)] = v;
+    }
+  } else if (game == 1) {  // w[0..3] = white pawns, white kings, black pawns, black kings, bit y*8+x
+    for (int p = 0; p < 64; ++p) {
+      int v = 0;
+      if ((w[0] >> p) & 1) v = 1;
+      else if ((w[1] >> p) & 1) v = 3;
+      else if ((w[2] >> p) & 1) v = -1;
+      else if ((w[3] >> p) & 1) v = -3;
+      g[(size_t)(p / 8)][(size_t)(p % 8)] = v;
+    }
+  } else if (game == 2) {  // w[0] = pieces[BLACK], w[1] = pieces[WHITE], bit y*8+x
+    for (int p = 0; p < 64; ++p) g[(size_t)(p / 8)][(size_t)(p % 8)] = ((w[0] >> p) & 1) ? 1 : ((w[1] >> p) & 1) ? -1 : 0;
+  } else {  // row r: low 32 bits black stones, high 32 bits white stones, bit = column
+    for (int r = 0; r < 19; ++r)
+      for (int c = 0; c < 19; ++c) g[(size_t)r][(size_t)c] = ((w[r] >> c) & 1) ? 1 : ((w[r] >> (32 + c)) & 1) ? -1 : 0;
+  }
+  return g;
+}
+
+inline std::string board_text(int game, const uint64_t* w, int current_player, int ply, int last_move) {
+  static const char* RED = "\u001b[31m"; static const char* GREEN = "\u001b[32m"; static const char* END = "\u001b[0m";
+  const auto g = board_grid(game, w);
+  const int n = (int)g.size();
+  std::stringstream ss;
+  for (int y = 0; y < n; ++y) {
+    for (int x = 0; x < n; ++x) {
+      int v = g[(size_t)y][(size_t)x];
+      if (game == 3) { ss << (v > 0 ? " X" : v < 0 ? " O" : " ."); continue; }
+      if (game == 1) v = -v;  // russian colours the white pieces red like the others, its grid holds them as positive
+      const char* piece = game == 2 ? "P" : (v == 3 || v == -3) ? "K" : "M";
+      if (v < 0) ss << RED; else if (v > 0) ss << GREEN;
+      ss << " (" << std::setw(2) << std::right << (y * n + x) << ")" << (v ? piece : "E");
+      if (v) ss << END;
+    }
+    ss << "\n";
+  }
+  if (game == 0) ss << "[" << w[0] << "][" << w[1] << "][" << w[2] << "][" << w[3] << "][" << (w[0] | w[2]) << "][" << (w[1] | w[3]) << "]\n";
+  if (game == 2) ss << "BLACK_PLAYER : " << std::hex << w[0] << "\nWHITE_PLAYER : " << w[1] << std::dec << "\n";
+  ss << "\nLast move\t: ";
+  if (last_move >= 0) ss << last_move; else ss << "Invalid";
+  ss << "\nCurrentPlayer\t: ";
+  if (current_player == 0) ss << GREEN << "Black" << END; else ss << RED << "White" << END;
+  ss << "\nmove num\t: " << ply << "\n";
+  return ss.str();
+}
+
+}  // namespace elfhip_view

@@ -19,6 +19,7 @@
 // elfhip_mcts_set_active), white overrides (white_puct, white_mcts_rollout_per_*), player_swap.
 // black/white_use_policy_network_only -> actPolicyOnly.  mode "play": the human side is served through
 // the "actor_white" batch (reply key "a": move, -100 not yet, -1 end game, -2 switch sides and end).
+#include "board_view.h"
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -162,6 +163,8 @@ struct ClientGameSelfPlay {  // common/ClientGameSelfPlay.h (console / GUI acces
   int idx = 0;
   int getCurrentPlayer() const;
   std::vector<int> getValidMoves() const;
+  std::vector<std::vector<int>> getBoard() const;
+  std::string showBoard() const;
   std::vector<uint64_t> getStateWords() const;
 };
 
@@ -370,6 +373,12 @@ class SelfPlayEngine : public elfhip_py::Engine {
   std::vector<uint64_t> state_of(int i) const {
     auto b = h_states_.begin() + (size_t)i * gi_.state_words;
     return std::vector<uint64_t>(b, b + gi_.state_words);
+  }
+  std::vector<std::vector<int>> board_of(int i) const { return elfhip_view::board_grid(game_, h_states_.data() + (size_t)i * gi_.state_words); }
+  std::string board_text_of(int i) const {
+    const auto& mv = cur_.at(i).moves;
+    return elfhip_view::board_text(game_, h_states_.data() + (size_t)i * gi_.state_words, h_player_.at(i), h_ply_.at(i),
+                                   mv.empty() ? -1 : (int)mv.back());
   }
   std::vector<int> valid_moves_of(int i) {
     need_running();
@@ -823,6 +832,8 @@ std::string DistriClient::onRequestJson(const std::string& js) {
 }
 int ClientGameSelfPlay::getCurrentPlayer() const { return eng->player_of(idx); }
 std::vector<int> ClientGameSelfPlay::getValidMoves() const { return eng->valid_moves_of(idx); }
+std::vector<std::vector<int>> ClientGameSelfPlay::getBoard() const { return eng->board_of(idx); }
+std::string ClientGameSelfPlay::showBoard() const { return eng->board_text_of(idx); }
 std::vector<uint64_t> ClientGameSelfPlay::getStateWords() const { return eng->state_of(idx); }
 
 class GameContext {  // elfgames/<game>/train/GameContext.h:46-160
@@ -913,6 +924,20 @@ PYBIND11_MODULE(ELFGAME_MODULE, m) {
   py::class_<ClientGameSelfPlay>(m, "ClientGameSelfPlay", py::module_local())
       .def("getCurrentPlayer", &ClientGameSelfPlay::getCurrentPlayer)
       .def("getValidMoves", &ClientGameSelfPlay::getValidMoves)
-      // the exported state words of include/elfhip.h instead of the reference's 8x8 int board
+      .def("getBoard", &ClientGameSelfPlay::getBoard)      // pybind/Pybind.cc:59 (8x8 ints; 19x19 for Go)
+      .def("showBoard", &ClientGameSelfPlay::showBoard)    // pybind/Pybind.cc:61
+      // no reference counterpart: the exported state words of include/elfhip.h
       .def("getStateWords", &ClientGameSelfPlay::getStateWords);
+  // no reference counterpart: the two views above from state words alone (needs no GPU; what the tests pin
+  // against the compiled reference's GetObservation)
+  m.def("boardFromStateWords", [](const std::vector<uint64_t>& w) {
+    elfhip_game_info gi;
+    if (elfhip_game_get_info(ELFGAME_ID, &gi) != 0 || (int)w.size() != gi.state_words) throw std::range_error("boardFromStateWords: wrong number of state words");
+    return elfhip_view::board_grid(ELFGAME_ID, w.data());
+  });
+  m.def("boardTextFromStateWords", [](const std::vector<uint64_t>& w, int current_player, int ply, int last_move) {
+    elfhip_game_info gi;
+    if (elfhip_game_get_info(ELFGAME_ID, &gi) != 0 || (int)w.size() != gi.state_words) throw std::range_error("boardTextFromStateWords: wrong number of state words");
+    return elfhip_view::board_text(ELFGAME_ID, w.data(), current_player, ply, last_move);
+  });
 }

@@ -1,0 +1,88 @@
+"""ClientGameSelfPlay.getBoard / showBoard of the facade modules (the accessors the reference's console and web
+front-ends read, pybind/Pybind.cc:57-64) decode the exported state words on the host.  The decode is pinned to
+tests/golden/board_views.json, boards the COMPILED reference's GetObservation(board, BLACK_PLAYER) produced along
+random playouts (tests/golden/make_board_views.py), and live against oracle/_ref where that was built."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import _gcwrapper, _oracle  # noqa: F401  (_gcwrapper puts elf_amd/pybind on sys.path)
+
+
+def _mods():
+    import _elfgames_american_checkers as am
+    import _elfgames_russian_checkers as ru
+    import _elfgames_ugolki as ug
+    return {"american": am, "russian": ru, "ugolki": ug}
+
+
+def test_get_board_decode_equals_the_compiled_reference_fixture(golden_dir):
+    gold = json.load(open(os.path.join(golden_dir, "board_views.json")))
+    mods = _mods()
+    for game, cases in gold.items():
+        assert len(cases) > 40
+        kinds = set()
+        for c in cases:
+            got = mods[game].boardFromStateWords(c["words"])
+            assert got == c["board"], (game, c["words"])
+            kinds |= set(np.unique(np.array(got)).tolist())
+        assert kinds >= ({-1, 0, 1} if game == "ugolki" else {-3, -1, 0, 1, 3}), (game, kinds)   # kings were reached
+
+
+def test_get_board_decode_live_against_the_compiled_reference():
+    am = _oracle.ref()
+    if am is None:
+        pytest.skip("oracle/_ref not built here")
+    mod = _mods()["american"]
+    rng = np.random.default_rng(21)
+    for g in range(10):
+        w = np.zeros(6, dtype=np.uint64)
+        am.ref_am_clear(w)
+        for ply in range(150):
+            obs = np.zeros(64, dtype=np.int32)
+            am.ref_am_observation(w, 0, obs)
+            assert mod.boardFromStateWords([int(x) for x in w]) == obs.reshape(8, 8).tolist()
+            v = np.zeros(170, dtype=np.int32)
+            am.ref_am_valid_moves(w, v)
+            legal = np.flatnonzero(v)
+            if am.ref_am_is_over(w) or len(legal) == 0:
+                break
+            am.ref_am_play(w, int(rng.choice(legal)))
+
+
+def test_show_board_text_has_the_reference_layout():
+    mods = _mods()
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "board_views.json")))
+    for game, mod in mods.items():
+        c = gold[game][0]
+        txt = mod.boardTextFromStateWords(c["words"], 0, 1, -1)
+        rows = txt.split("\n")
+        assert all(r.count("(") == 8 for r in rows[:8])
+        # the start position: square 63's cell as the reference prints it, plain "E" cells uncoloured
+        assert " ( 0)" in rows[0] and "(63)" in rows[7]
+        assert "Last move\t: Invalid" in txt and "CurrentPlayer\t: \u001b[32mBlack\u001b[0m" in txt and txt.endswith("move num\t: 1\n")
+        piece = "P" if game == "ugolki" else "M"
+        n_green = txt.count("\u001b[32m (") ; n_red = txt.count("\u001b[31m (")
+        b = np.array(c["board"])
+        if game == "russian":       # board.board holds white as positive; white is printed red
+            assert (n_red, n_green) == (int((b > 0).sum()), int((b < 0).sum()))
+        else:
+            assert (n_green, n_red) == (int((b > 0).sum()), int((b < 0).sum()))
+        assert txt.count(")" + piece) == int((b != 0).sum())
+        txt2 = mod.boardTextFromStateWords(c["words"], 1, 7, 42)
+        assert "Last move\t: 42" in txt2 and "\u001b[31mWhite\u001b[0m" in txt2 and "move num\t: 7" in txt2
+    with pytest.raises(Exception):
+        mods["american"].boardFromStateWords([0, 0, 0])
+
+
+def test_go_board_view():
+    import _elfgames_go as go
+    w = [0] * 22
+    w[3] = (1 << 4) | (1 << (32 + 5))          # row 3: black at column 4, white at column 5
+    g = go.boardFromStateWords(w)
+    assert len(g) == 19 and len(g[0]) == 19
+    assert g[3][4] == 1 and g[3][5] == -1 and sum(abs(x) for r in g for x in r) == 2
+    txt = go.boardTextFromStateWords(w, 1, 3, 61)
+    assert txt.split("\n")[3].split() == ["."] * 4 + ["X", "O"] + ["."] * 13

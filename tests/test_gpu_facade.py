@@ -94,6 +94,15 @@ def test_facade_selfplay_matches_oracle(batchsize):
     g = GC.getGame(0)
     vm = g.getValidMoves()
     assert len(vm) == 170 and sum(vm) > 0 and g.getCurrentPlayer() in (0, 1)
+    # the front-end accessors (pybind/Pybind.cc:59-61): the live game's board is the decode of its state words
+    # (pinned to the compiled reference in tests/test_board_views.py), and the piece counts agree with them
+    brd = g.getBoard()
+    sw = g.getStateWords()
+    import _elfgames_american_checkers as ac
+    assert brd == ac.boardFromStateWords(sw) and len(brd) == 8
+    assert sum(1 for r in brd for v in r if v) == bin(sw[0] | sw[1] | sw[2] | sw[3]).count("1")
+    txt = g.showBoard()
+    assert txt.count("(") == 64 and ("Black" if g.getCurrentPlayer() == 0 else "White") in txt
     w.stop()
     assert GC.ctx().wait() is None
 
