@@ -54,6 +54,22 @@ def main():
 
     w.reg_callback("actor_black", actor)
     w.start()
+    if os.environ.get("ELF_BENCH_KEEP_WARM"):
+        # diagnostic only: a side stream of matrix products keeps the GPU's clocks up while the 64-tree loop leaves
+        # it nearly idle (the same run under rocprofv3 is several times faster)
+        import threading
+        stop = threading.Event()
+
+        def warm():
+            side = torch.cuda.Stream()
+            a_ = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+            with torch.cuda.stream(side):
+                while not stop.is_set():
+                    for _ in range(4):
+                        a_ @ a_
+                    side.synchronize()
+        th = threading.Thread(target=warm, daemon=True)
+        th.start()
 
     def ply():
         return (GC.getGame(0).getStateWords()[20] >> 16) & 0xFFFF
@@ -75,7 +91,7 @@ def main():
                                              "%d leaves/batch, 2-block x 32 ResNet as a Python actor (BASELINE.json configs[0])"
                                              % (a.games, a.rollouts, a.leaves), "batchsize": a.batchsize, "moves_timed": a.moves},
                       "rows_served": rows[0], "rollouts_all_per_sec": (s1["rollouts"] - s0["rollouts"]) / dt,
-                      "seconds": dt, "seconds_in_python_actor": t_model[0]}), flush=True)
+                      "seconds": dt, "seconds_in_python_actor": t_model[0], "host_ms": {k: round(s1["host_ms"][k] - s0["host_ms"][k], 1) for k in s1["host_ms"]}}), flush=True)
     w.stop()
 
 

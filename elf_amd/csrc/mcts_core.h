@@ -196,6 +196,98 @@ struct ExpandScratch {
 // (MCTSGameActor.h:198-335): pi2response = std::sort all (action, pi) pairs descending, keep the legal
 // ones, normalise; the edges are then stored in std::unordered_map iteration order.
 // pi == nullptr selects the uniform evaluator (pi = 1/NA).  mk = legal mask words of the leaf.
+// Two parts so that the waves of one workgroup can prepare different leaves of a tree at the same time and
+// then take their edge ranges in slot order: expand_prepare works in its own scratch only and returns the number
+// of edges (-1: more legal moves than MAXLEGAL); expand_commit writes the edge records and the node header.
+// Both synchronise the calling wave only (stdorder::wave_sync).
+template <int NA, int MAXLEGAL>
+__device__ inline int expand_prepare(const TreeDev& d, const uint64_t* mk, const float* __restrict__ pi, int lane,
+                                     ExpandScratch<NA, MAXLEGAL>& S) {
+  if (pi) {
+    for (int i = lane; i < NA; i += 64) { S.items[i].key = pi[i]; S.items[i].idx = (uint16_t)i; }
+  } else {
+    for (int i = lane; i < NA; i += 64) { S.items[i].key = 1.0f / (float)NA; S.items[i].idx = d.uniform_order[i]; }
+  }
+  stdorder::wave_sync();
+  // std::sort descending by pi (MCTSGameActor.h:295-300).  With distinct keys the result is THE descending
+  // order whatever the algorithm, so the wave rank-sorts in parallel (rank = number of larger keys, every lane
+  // scans all NA keys as LDS broadcasts).  std::sort is not stable: only when two keys are equal (or a key is
+  // NaN) does the order depend on libstdc++'s introsort, and then lane 0 runs its exact emulation as before
+  // (a single lane's dependent LDS round trips made that ~0.5 ms per Go leaf).
+  const stdorder::Item* sorted = S.items;
+  if (pi) {
+    bool odd = false;
+    for (int c = 0; c < NA; c += 64) {
+      const int i = c + lane;
+      const bool in = i < NA;
+      const float ki = S.items[in ? i : 0].key;
+      int rank = 0, same = 0;
+      for (int j = 0; j < NA; ++j) {
+        const float kj = S.items[j].key;
+        rank += kj > ki ? 1 : 0;
+        same += kj == ki ? 1 : 0;
+      }
+      if (in) {
+        if (same != 1) odd = true;
+        else S.sorted[rank] = S.items[i];
+      }
+    }
+    if (__any(odd)) {
+      stdorder::wave_sync();
+      if (lane == 0) stdorder::sort_desc(S.items, NA);
+    } else {
+      sorted = S.sorted;
+    }
+    stdorder::wave_sync();
+  }
+  // checkMove filter (:305-331): the legal items keep their sorted order.  Lanes test 64 items at a
+  // time; an item's slot is the number of legal items before it (ballot + popcount).
+  int kept = 0;
+  for (int c = 0; c < NA; c += 64) {
+    const int i = c + lane;
+    const bool in = i < NA;
+    const int a = in ? (int)sorted[in ? i : 0].idx : 0;
+    uint64_t word = 0;
+#pragma unroll
+    for (int q = 0; q < (NA + 63) / 64; ++q) word = (a >> 6) == q ? mk[q] : word;
+    const bool legal = in && ((word >> (a & 63)) & 1);
+    const unsigned long long b = __ballot(legal);
+    const int pos = kept + __popcll(b & ((1ull << lane) - 1ull));
+    if (legal && pos < MAXLEGAL) { S.keys[pos] = (uint16_t)a; S.pri[pos] = sorted[i].key; }
+    kept += __popcll(b);
+  }
+  stdorder::wave_sync();
+  // normalize (:240-251): the sum in the reference's order (every lane adds the same LDS broadcasts), the
+  // divisions one element per lane; then the hashtable order, a wave-parallel pass per bucket count
+  const bool over = kept > MAXLEGAL;
+  const int mm = over ? MAXLEGAL : kept;
+  float tot = 1e-10f;
+  for (int k = 0; k < mm; ++k) tot += S.pri[k];
+  stdorder::wave_sync();
+  for (int k = lane; k < mm; k += 64) S.pri[k] /= tot;
+  stdorder::umap_iteration_order_wave(S.keys, mm, lane, S.seq, S.rkey, S.table, S.pos);
+  stdorder::wave_sync();
+  return over ? -1 : mm;
+}
+
+template <int NA, int MAXLEGAL>
+__device__ inline void expand_commit(TV& tv, int leaf, bool flip, float value, int eb, int m, int lane,
+                                     const ExpandScratch<NA, MAXLEGAL>& S) {
+  for (int j = lane; j < m; j += 64) {
+    const int p = S.pos[j];
+    // one 24-byte edge record = three 8-byte stores: {prior, child -1} {reward 0, visits 0} {vloss 0, action}
+    uint2* rec = (uint2*)(tv.ep.p + (size_t)(eb + j) * EDGE_BYTES);
+    rec[0] = make_uint2(__float_as_uint(S.pri[p]), 0xFFFFFFFFu);
+    rec[1] = make_uint2(0u, 0u);
+    rec[2] = make_uint2(0u, (uint32_t)S.keys[p]);
+  }
+  // first half of the header in one store; a node that was never VISITED has no children, so numVisits is 0
+  *(uint4*)(tv.meta.p + (size_t)leaf * NODE_BYTES) =
+      make_uint4(VISITED | (flip ? META_FLIP : 0u) | META_STATE_SET | ((uint32_t)m << 16), (uint32_t)eb, 0u, __float_as_uint(value));
+  stdorder::wave_sync();   // the scratch is free for the next leaf, the stores are ordered before what follows
+}
+
+// one leaf after the other on one wave (the checkers-family kernels)
 template <int NA, int MAXLEGAL>
 __device__ inline void expand_edges(const TreeDev& d, TV& tv, int leaf, bool terminal, bool flip, float value,
                                     const uint64_t* mk, const float* __restrict__ pi, int lane, int& ne_cnt, int& flags,
@@ -204,89 +296,13 @@ __device__ inline void expand_edges(const TreeDev& d, TV& tv, int leaf, bool ter
   const int eb = ne_cnt;
   if (!terminal) {
     evals += 1;
-    if (pi) {
-      for (int i = lane; i < NA; i += 64) { S.items[i].key = pi[i]; S.items[i].idx = (uint16_t)i; }
-    } else {
-      for (int i = lane; i < NA; i += 64) { S.items[i].key = 1.0f / (float)NA; S.items[i].idx = d.uniform_order[i]; }
-    }
-    __syncthreads();
-    // std::sort descending by pi (MCTSGameActor.h:295-300).  With distinct keys the result is THE descending
-    // order whatever the algorithm, so the wave rank-sorts in parallel (rank = number of larger keys, every lane
-    // scans all NA keys as LDS broadcasts).  std::sort is not stable: only when two keys are equal (or a key is
-    // NaN) does the order depend on libstdc++'s introsort, and then lane 0 runs its exact emulation as before
-    // (a single lane's dependent LDS round trips made that ~0.5 ms per Go leaf).
-    const stdorder::Item* sorted = S.items;
-    if (pi) {
-      bool odd = false;
-      for (int c = 0; c < NA; c += 64) {
-        const int i = c + lane;
-        const bool in = i < NA;
-        const float ki = S.items[in ? i : 0].key;
-        int rank = 0, same = 0;
-        for (int j = 0; j < NA; ++j) {
-          const float kj = S.items[j].key;
-          rank += kj > ki ? 1 : 0;
-          same += kj == ki ? 1 : 0;
-        }
-        if (in) {
-          if (same != 1) odd = true;
-          else S.sorted[rank] = S.items[i];
-        }
-      }
-      if (__any(odd)) {
-        __syncthreads();
-        if (lane == 0) stdorder::sort_desc(S.items, NA);
-      } else {
-        sorted = S.sorted;
-      }
-      __syncthreads();
-    }
-    // checkMove filter (:305-331): the legal items keep their sorted order.  Lanes test 64 items at a
-    // time; an item's slot is the number of legal items before it (ballot + popcount).
-    int kept = 0;
-    for (int c = 0; c < NA; c += 64) {
-      const int i = c + lane;
-      const bool in = i < NA;
-      const int a = in ? (int)sorted[in ? i : 0].idx : 0;
-      uint64_t word = 0;
-#pragma unroll
-      for (int q = 0; q < (NA + 63) / 64; ++q) word = (a >> 6) == q ? mk[q] : word;
-      const bool legal = in && ((word >> (a & 63)) & 1);
-      const unsigned long long b = __ballot(legal);
-      const int pos = kept + __popcll(b & ((1ull << lane) - 1ull));
-      if (legal && pos < MAXLEGAL) { S.keys[pos] = (uint16_t)a; S.pri[pos] = sorted[i].key; }
-      kept += __popcll(b);
-    }
-    __syncthreads();
-    // normalize (:240-251): the sum in the reference's order (every lane adds the same LDS broadcasts), the
-    // divisions one element per lane; then the hashtable order, a wave-parallel pass per bucket count
-    const bool over = kept > MAXLEGAL;
-    const int mm = over ? MAXLEGAL : kept;
-    float tot = 1e-10f;
-    for (int k = 0; k < mm; ++k) tot += S.pri[k];
-    __syncthreads();
-    for (int k = lane; k < mm; k += 64) S.pri[k] /= tot;
-    stdorder::umap_iteration_order_wave(S.keys, mm, lane, S.seq, S.rkey, S.table, S.pos);
-    __syncthreads();
-    m = over ? -1 : mm;
+    m = expand_prepare<NA, MAXLEGAL>(d, mk, pi, lane, S);
     if (m < 0) { flags |= FLAG_LEGAL_OVERFLOW; m = 0; }
     if (eb + m > d.max_edges) { flags |= FLAG_EDGE_OVERFLOW; m = 0; }
-    for (int j = lane; j < m; j += 64) {
-      const int p = S.pos[j];
-      // one 24-byte edge record = three 8-byte stores: {prior, child -1} {reward 0, visits 0} {vloss 0, action}
-      uint2* rec = (uint2*)(tv.ep.p + (size_t)(eb + j) * EDGE_BYTES);
-      rec[0] = make_uint2(__float_as_uint(S.pri[p]), 0xFFFFFFFFu);
-      rec[1] = make_uint2(0u, 0u);
-      rec[2] = make_uint2(0u, (uint32_t)S.keys[p]);
-    }
-    __syncthreads();
     ne_cnt += m;
     edge_sum += (unsigned long long)m;
   }
-  // first half of the header in one store; a node that was never VISITED has no children, so numVisits is 0
-  *(uint4*)(tv.meta.p + (size_t)leaf * NODE_BYTES) =
-      make_uint4(VISITED | (flip ? META_FLIP : 0u) | META_STATE_SET | ((uint32_t)m << 16), (uint32_t)eb, 0u, __float_as_uint(value));
-  __threadfence_block();
+  expand_commit<NA, MAXLEGAL>(tv, leaf, flip, value, eb, m, lane, S);
 }
 
 // backup of one batch (tree_search.h:291-305 + updateEdgeStats tree_search_node.h:267-292):
@@ -313,8 +329,7 @@ __device__ inline void backup_batch(const TreeDev& d, TV& tv, const Opt& o, int 
       *rv = make_uint2(__float_as_uint(__uint_as_float(x.x) + reward), x.y + 1u);
       tv.el[e] = tv.el[e] - (float)(o.vl * count);
     }
-    __threadfence_block();
-    __syncthreads();
+    stdorder::wave_sync();   // called by ONE wave of the workgroup: trajectories stay in order
   }
 }
 

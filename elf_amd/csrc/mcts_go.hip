@@ -242,31 +242,64 @@ go_tree_features_kernel(TreeDev d, Opt o, GoDev g, const uint8_t* __restrict__ n
   dst[(size_t)17 * GO_POINTS + p] = tm == 1 ? 1.f : 0.f;
 }
 
-// step 4: setEvaluation of the locked leaves + backup of the batch
-__global__ void __launch_bounds__(64)
+// step 4: setEvaluation of the locked leaves + backup of the batch.  One workgroup per tree, one wave per
+// leaf (up to BACKUP_WAVES at a time): the waves prepare their leaves' edge lists side by side, each in its own
+// LDS scratch, then take their edge ranges in slot order (the order the reference's threads-of-one would have
+// expanded them in) and write them; wave 0 then runs the batch's updateEdgeStats.
+constexpr int BACKUP_WAVES = 8;
+__global__ void __launch_bounds__(64 * BACKUP_WAVES)
 go_tree_backup_kernel(TreeDev d, Opt o, GoX x, const float* __restrict__ pi, const float* __restrict__ vin) {
-  __shared__ GoScratch S;
+  extern __shared__ __attribute__((aligned(16))) char go_backup_smem[];
   __shared__ int s_leaf[MAXB];
   __shared__ int s_locked[MAXB];
-  const int t = blockIdx.x, lane = threadIdx.x;
+  __shared__ int s_m[MAXB];
+  const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+  GoScratch& S = ((GoScratch*)go_backup_smem)[wave];
   int flags = d.t_flags[t];
   if (flags) return;
   TV tv = tree_view(d, t, d.t_arena[t]);
   int ne = d.t_nedges[t];
   unsigned long long evals = 0, edge_sum = 0;
-  if (lane < o.B) { s_leaf[lane] = d.leaf[(size_t)t * o.B + lane]; s_locked[lane] = d.locked[(size_t)t * o.B + lane]; }
+  if ((int)threadIdx.x < o.B) { s_leaf[threadIdx.x] = d.leaf[(size_t)t * o.B + threadIdx.x]; s_locked[threadIdx.x] = d.locked[(size_t)t * o.B + threadIdx.x]; }
   __syncthreads();
-  for (int j = 0; j < o.B; ++j) {
-    if (!s_locked[j]) continue;
-    const size_t slot = (size_t)t * o.B + j;
-    const bool terminal = x.leaf_term[slot] != 0;
-    const float value = terminal ? x.leaf_tval[slot] : (vin ? vin[slot] : 0.0f);
-    expand_edges<NA, NA>(d, tv, s_leaf[j], terminal, x.leaf_flip[slot] != 0, value, x.leaf_mask + slot * 6,
-                         pi ? pi + slot * NA : nullptr, lane, ne, flags, S, evals, edge_sum);
+  for (int j0 = 0; j0 < o.B; j0 += W) {
+    const int j = j0 + wave;
+    const bool have = j < o.B && s_locked[j < o.B ? j : 0];
+    const size_t slot = (size_t)t * o.B + (have ? j : 0);
+    bool terminal = true;
+    float value = 0.0f;
+    int m = 0;
+    if (have) {
+      terminal = x.leaf_term[slot] != 0;
+      value = terminal ? x.leaf_tval[slot] : (vin ? vin[slot] : 0.0f);
+      if (!terminal) {
+        evals += 1;
+        m = expand_prepare<NA, NA>(d, x.leaf_mask + slot * 6, pi ? pi + slot * NA : nullptr, lane, S);
+      }
+    }
+    if (lane == 0 && j < o.B) s_m[j] = m;
+    __syncthreads();
+    // edge ranges in slot order; every wave walks the same counts, so `ne` and `flags` agree in all of them
+    int my_eb = ne, my_m = 0;
+    const int jend = j0 + W < o.B ? j0 + W : o.B;
+    for (int k = j0; k < jend; ++k) {
+      int mk = s_m[k];
+      if (mk < 0) { flags |= FLAG_LEGAL_OVERFLOW; mk = 0; }
+      if (ne + mk > d.max_edges) { flags |= FLAG_EDGE_OVERFLOW; mk = 0; }
+      if (k == j) { my_eb = ne; my_m = mk; }
+      ne += mk;
+    }
+    if (have) {
+      expand_commit<NA, NA>(tv, s_leaf[j], x.leaf_flip[slot] != 0, value, my_eb, my_m, lane, S);
+      edge_sum += (unsigned long long)my_m;
+    }
+    __syncthreads();
   }
-  backup_batch(d, tv, o, t, s_leaf);
+  __threadfence_block();
+  __syncthreads();
+  if (wave == 0) backup_batch(d, tv, o, t, s_leaf);
   if (lane == 0) {
-    d.t_nedges[t] = ne; d.t_flags[t] = flags;
+    if (wave == 0) { d.t_nedges[t] = ne; d.t_flags[t] = flags; }
     if (evals) atomicAdd(&d.stats[1], evals);
     if (edge_sum) atomicAdd(&d.stats[3], edge_sum);
   }
@@ -283,6 +316,8 @@ struct GoMcts : MctsBase {
     const size_t S = (size_t)n_trees * opt->num_rollouts_per_batch;
     MCTS_ALLOC(x.leaf_mask, S * 6 * 8); MCTS_ALLOC(x.leaf_term, S); MCTS_ALLOC(x.leaf_flip, S); MCTS_ALLOC(x.leaf_tval, S * 4);
     MCTS_ALLOC(own_need, S);
+    static_assert(sizeof(GoScratch) * BACKUP_WAVES <= 150 * 1024, "backup scratch must fit the CU's LDS");
+    HIPCHECK(hipFuncSetAttribute((const void*)go_tree_backup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(GoScratch) * BACKUP_WAVES)));
     return alloc_common(n_trees, opt, NA, GO_SW, 256);
   }
   int set_roots(BoardSlab* slab, uint8_t* d_ok) override {
@@ -305,7 +340,10 @@ struct GoMcts : MctsBase {
     return ELFHIP_OK;
   }
   int backup(const float* d_pi, const float* d_value) override {
-    hipLaunchKernelGGL(go_tree_backup_kernel, dim3(d.n_trees), dim3(64), 0, stream, d, o, x, d_pi, d_value);
+    // few trees: a wave per leaf (latency: 2.3 -> 0.3 ms per batch at 64 trees); many trees: the chip is full with
+    // one wave per tree and twelve trees per CU fit the LDS (4,096 trees: 2.7 ms against 5.1 ms with 8 waves)
+    const int waves = d.n_trees > 1024 ? 1 : (o.B < BACKUP_WAVES ? o.B : BACKUP_WAVES);
+    hipLaunchKernelGGL(go_tree_backup_kernel, dim3(d.n_trees), dim3(64 * waves), sizeof(GoScratch) * waves, stream, d, o, x, d_pi, d_value);
     HIPCHECK(hipGetLastError());
     return ELFHIP_OK;
   }

@@ -206,22 +206,30 @@ ELF_HD void umap_iteration_order(const uint16_t* keys, int m, int16_t* next, int
 // S, descending) - a rank every lane can count for its elements.  One such pass per bucket count 13 .. 541.
 // keys[0..m), m <= 512, all arrays in LDS: seq uint16[m], rkey int[(m+3)&~3] (16-byte aligned), table int[>= bucket
 // count].  out[0..m) receives positions as above.  Every lane of the wave must call it.
+// Orders the calling wave's LDS / memory accesses before and after it (lanes of a wave run in lockstep, so no
+// barrier instruction is needed; the fence keeps the compiler and the wait counters honest).  Used instead of
+// __syncthreads() so that several waves of one workgroup can run these routines on different data.
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <int NB>
 __device__ inline void umap_epoch_wave(const uint16_t* keys, int cnt, int end, int lane, const uint16_t* src, uint16_t* dst,
                                        int* rkey, int* table) {
   for (int b = lane; b < NB; b += 64) table[b] = 0x7fffffff;
-  __syncthreads();
+  wave_sync();
   for (int i = lane; i < end; i += 64) {
     const int p = i < cnt ? (int)src[i] : i;
     atomicMin(&table[(int)keys[p] % NB], i);
   }
-  __syncthreads();
+  wave_sync();
   const int end4 = (end + 3) & ~3;
   for (int i = lane; i < end4; i += 64) {
     const int p = i < cnt ? (int)src[i] : i;
     rkey[i] = i < end ? table[(int)keys[p] % NB] * 1024 + i : (int)0x80000000;
   }
-  __syncthreads();
+  wave_sync();
   for (int c = 0; c < end; c += 64) {
     const int i = c + lane;
     const bool in = i < end;
@@ -233,7 +241,7 @@ __device__ inline void umap_epoch_wave(const uint16_t* keys, int cnt, int end, i
     }
     if (in) dst[before] = (uint16_t)(i < cnt ? (int)src[i] : i);
   }
-  __syncthreads();
+  wave_sync();
 }
 
 __device__ inline void umap_iteration_order_wave(const uint16_t* keys, int m, int lane, uint16_t* seq, int* rkey, int* table,

@@ -19,6 +19,7 @@
 // elfhip_mcts_set_active), white overrides (white_puct, white_mcts_rollout_per_*), player_swap.
 // black/white_use_policy_network_only -> actPolicyOnly.  mode "play": the human side is served through
 // the "actor_white" batch (reply key "a": move, -100 not yet, -1 end game, -2 switch sides and end).
+#include <chrono>
 #include "board_view.h"
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -168,6 +169,16 @@ struct ClientGameSelfPlay {  // common/ClientGameSelfPlay.h (console / GUI acces
   std::vector<uint64_t> getStateWords() const;
 };
 
+// wall-clock split of the host loop (GameContext.searchStats()["host_ms"]); always on, a clock read per phase
+struct PhaseClock {
+  double ms[6] = {0, 0, 0, 0, 0, 0};  // select, serve, reply, backup, move, begin
+  struct Scope {
+    double& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit Scope(double& a) : acc(a) {}
+    ~Scope() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+  };
+};
+
 class SelfPlayEngine : public elfhip_py::Engine {
  public:
   SelfPlayEngine(int game, const ContextOptions& co, const GameOptions& go) : game_(game), co_(co), go_(go) {
@@ -228,6 +239,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
     if (play_mode() && !label("actor_white"))
       throw std::runtime_error("GameContext: mode 'play' needs an 'actor_white' batch for the human side (game.py:346-363)");
     hk(hipSetDevice(device_), "hipSetDevice");
+    pin_batches();
     n_ = co_.num_games;
     ck(elfhip_boards_create(game_, n_, device_, &boards_), "boards_create");
     build_ais();
@@ -273,7 +285,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
               break;
             }
           }
-          begin_move();
+          { PhaseClock::Scope sc(clock_.ms[5]); begin_move(); }
           break;
         case HUMAN: return serve_human();
         case SELECT: {
@@ -282,6 +294,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
           if (rollouts_ == 0) set_active(jb.ai, jb.mask);
           if (rollouts_ >= jb.need) { ++job_; rollouts_ = 0; break; }
           const int B = spec_[jb.ai].B;
+          PhaseClock::Scope sc(clock_.ms[0]);
           ck(elfhip_mcts_select(mcts_[jb.ai], nullptr, (float*)d_feat_, (uint8_t*)d_need_), "mcts_select");
           h_need_.resize((size_t)n_ * B);
           hk(hipMemcpy(h_need_.data(), d_need_, h_need_.size(), hipMemcpyDeviceToHost), "copy need");
@@ -292,16 +305,17 @@ class SelfPlayEngine : public elfhip_py::Engine {
           phase_ = h_idx_.empty() ? BACKUP : SERVE;
           break;
         }
-        case SERVE: return serve_chunk();
+        case SERVE: { PhaseClock::Scope sc(clock_.ms[1]); return serve_chunk(); }
         case BACKUP: {
           const Job& jb = jobs_[job_];
+          PhaseClock::Scope sc(clock_.ms[3]);
           ck(elfhip_mcts_backup(mcts_[jb.ai], (const float*)d_pi_, (const float*)d_v_), "mcts_backup");
           rollouts_ += spec_[jb.ai].B;
           phase_ = SELECT;
           break;
         }
         case MOVE:
-          make_moves();
+          { PhaseClock::Scope sc(clock_.ms[4]); make_moves(); }
           phase_ = BEGIN;
           break;
       }
@@ -313,14 +327,15 @@ class SelfPlayEngine : public elfhip_py::Engine {
     serving_ = nullptr;
     hk(hipSetDevice(device_), "hipSetDevice");
     if (phase_ == HUMAN) { human_reply(m, success); return; }
+    PhaseClock::Scope sc(clock_.ms[2]);
     const int k = chunk_n_;
     const size_t A = gi_.num_actions;
     AnyP* pi = key(m, "pi");
     AnyP* v = key(m, "V");
     if (success && pi && v) {
       // ReplyPolicy / ReplyValue (common/GameFeature.h:40-62): rows [0,k) of the caller's tensors
-      hk(hipMemcpy2D(d_cpi_, A * 4, pi->row(0), (size_t)pi->strides.at(0), A * 4, k, hipMemcpyHostToDevice), "copy pi");
-      hk(hipMemcpy2D(d_cv_, 4, v->row(0), (size_t)v->strides.at(0), 4, k, hipMemcpyHostToDevice), "copy V");
+      copy_rows(d_cpi_, pi, A * 4, k, true, "copy pi");
+      copy_rows(d_cv_, v, 4, k, true, "copy V");
     } else {  // step(FAILED): "act unsuccessful", the leaf keeps an empty policy (MCTSGameActor.h:122-124)
       hk(hipMemset(d_cpi_, 0, (size_t)k * A * 4), "memset");
       hk(hipMemset(d_cv_, 0, (size_t)k * 4), "memset");
@@ -457,6 +472,10 @@ class SelfPlayEngine : public elfhip_py::Engine {
     }
     py::dict d;
     d["rollouts"] = st[0]; d["evals"] = st[1]; d["depth_sum"] = st[2]; d["edge_sum"] = st[3];
+    py::dict h;  // where the host loop's wall time went since start (each phase includes the GPU waits inside it)
+    h["select"] = clock_.ms[0]; h["serve"] = clock_.ms[1]; h["reply"] = clock_.ms[2]; h["backup"] = clock_.ms[3];
+    h["move"] = clock_.ms[4]; h["begin"] = clock_.ms[5];
+    d["host_ms"] = h;
     return d;
   }
   // which AIs exist and what they run with (ClientGameSelfPlay::restart / init_ai)
@@ -491,7 +510,37 @@ class SelfPlayEngine : public elfhip_py::Engine {
     (void)hipFree(p);
     p = nullptr;
   }
+  // The caller's batch arrays are page-locked for the life of the context, as the reference's GCWrapper does with
+  // pin_memory() (rlpytorch utils_elf.py allocExtractor): a copy to or from pageable memory is staged by the runtime
+  // page by page (measured per 512-row Go batch: policy + value in 8.5 ms -> 0.05 ms, the 13-MB feature rows out in
+  // 3.9 ms -> 0.7 ms once registered).  Best effort: memory that
+  // is already pinned (torch pinned tensors) or cannot be registered is used as it is.
+  void pin_batches() {
+    for (auto& kv : by_label_)
+      for (auto* m : kv.second)
+        for (auto& kp : m->mem) {
+          AnyP& a = kp.second;
+          if (!a.ptr || a.strides.empty()) continue;
+          const size_t bytes = (size_t)a.strides[0] * (size_t)std::max(1, m->opts.batchsize);
+          void* p = (void*)(uintptr_t)a.ptr;
+          if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) pinned_.push_back(p);
+          else (void)hipGetLastError();
+        }
+  }
+  // rows [0,k) of a caller's array <-> a dense device buffer
+  void copy_rows(void* dev, const AnyP* a, size_t row_bytes, int k, bool to_device, const char* what) {
+    const size_t stride = (size_t)a->strides.at(0);
+    if (stride == row_bytes || k == 1) {
+      hk(to_device ? hipMemcpy(dev, a->row(0), row_bytes * (size_t)k, hipMemcpyHostToDevice)
+                   : hipMemcpy(a->row(0), dev, row_bytes * (size_t)k, hipMemcpyDeviceToHost), what);
+    } else {
+      hk(to_device ? hipMemcpy2D(dev, row_bytes, a->row(0), stride, row_bytes, (size_t)k, hipMemcpyHostToDevice)
+                   : hipMemcpy2D(a->row(0), stride, dev, row_bytes, row_bytes, (size_t)k, hipMemcpyDeviceToHost), what);
+    }
+  }
   void release() {
+    for (void* p : pinned_) (void)hipHostUnregister(p);
+    pinned_.clear();
     for (auto& m : mcts_) if (m) { elfhip_mcts_destroy(m); m = nullptr; }
     if (boards_) { elfhip_boards_destroy(boards_); boards_ = nullptr; }
     for (void* p : allocs_) (void)hipFree(p);
@@ -608,7 +657,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
     if (AnyP* s = key(m, "s")) {
       // extractGameState -> BoardFeature::extract (GameFeature.h:28-32): leaf planes, one row per state
       ck(elfhip_gather_rows(d_feat_, (long long)feat_row_, idx, k, d_cfeat_, device_, nullptr), "gather s");
-      hk(hipMemcpy2D(s->row(0), (size_t)s->strides.at(0), d_cfeat_, feat_row_, feat_row_, k, hipMemcpyDeviceToHost), "copy s");
+      copy_rows(d_cfeat_, s, feat_row_, k, false, "copy s");
     }
     if (AnyP* g = m->get("game_idx"))
       for (int i = 0; i < k; ++i) *(int32_t*)g->row(i) = h_idx_[cursor_ + i] / B;
@@ -769,6 +818,8 @@ class SelfPlayEngine : public elfhip_py::Engine {
   std::vector<uint8_t> h_need_, h_pol_, h_ok_, h_term_, h_owner_, h_ponly_, h_human_, h_m8_, h_force_end_, h_skip_;
   std::vector<uint64_t> h_states_, h_lmask_;
   std::vector<int32_t> h_ply_, h_idx_, h_nedges_;
+  PhaseClock clock_;
+  std::vector<void*> pinned_;
   std::vector<int> h_player_, hcur_;
   std::vector<int16_t> h_move_, h_hmove_;
   std::vector<float> h_val_, h_reward_;
