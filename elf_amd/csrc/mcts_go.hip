@@ -15,6 +15,7 @@
 //   4. go_tree_backup_kernel   wave per tree : pi2response + setEvaluation per new leaf, then the
 //                                              batch's updateEdgeStats
 // Node positions are 64 x u32 per node (black / white / atari rows, meta, captures, hash).
+#include <stdlib.h>
 #include "go_dev.h"
 #include "mcts_core.h"
 
@@ -342,7 +343,11 @@ struct GoMcts : MctsBase {
   int backup(const float* d_pi, const float* d_value) override {
     // few trees: a wave per leaf (latency: 2.3 -> 0.3 ms per batch at 64 trees); many trees: the chip is full with
     // one wave per tree and twelve trees per CU fit the LDS (4,096 trees: 2.7 ms against 5.1 ms with 8 waves)
-    const int waves = d.n_trees > 1024 ? 1 : (o.B < BACKUP_WAVES ? o.B : BACKUP_WAVES);
+    int waves = d.n_trees > 1024 ? 1 : (o.B < BACKUP_WAVES ? o.B : BACKUP_WAVES);
+    if (const char* e = getenv("ELFHIP_GO_BACKUP_WAVES")) {   // tests: both shapes on the same small search
+      const int w = atoi(e);
+      if (w >= 1 && w <= BACKUP_WAVES) waves = w;
+    }
     hipLaunchKernelGGL(go_tree_backup_kernel, dim3(d.n_trees), dim3(64 * waves), sizeof(GoScratch) * waves, stream, d, o, x, d_pi, d_value);
     HIPCHECK(hipGetLastError());
     return ELFHIP_OK;

@@ -119,6 +119,15 @@ def test_go_scripted_network_batch1_and_batch8(torch_cuda):
           policy_kind=1, seed=5, start_plies=60, max_nodes=512, max_edges=160000)
 
 
+@pytest.mark.parametrize("waves", [1, 3, 8])
+def test_go_backup_shapes_give_the_same_trees(torch_cuda, waves, monkeypatch):
+    """go_tree_backup_kernel runs a wave per tree above 1,024 trees and a wave per leaf below; both shapes (and
+    a wave count that does not divide the batch) must build the oracle's trees on the same search."""
+    monkeypatch.setenv("ELFHIP_GO_BACKUP_WAVES", str(waves))
+    _play(torch_cuda, 5, 3, dict(num_rollouts_per_thread=48, num_rollouts_per_batch=8, virtual_loss=1, c_puct=1.5),
+          policy_kind=1, seed=17, start_plies=50, max_nodes=512, max_edges=160000)
+
+
 def test_go_late_game_captures_ko_and_passes(torch_cuda):
     """Crowded boards: captures, ko and suicide exclusions inside the tree; pass edges get visited
     so two-pass terminal leaves (Tromp-Taylor value) occur."""
