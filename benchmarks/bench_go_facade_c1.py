@@ -22,14 +22,22 @@ def main():
     ap.add_argument("--leaves", type=int, default=8)
     ap.add_argument("--batchsize", type=int, default=512)
     ap.add_argument("--moves", type=int, default=8)
+    ap.add_argument("--game", default="go", choices=["go", "american", "russian", "ugolki"],
+                    help="go = BASELINE.json configs[0]; the checkers-family modules run the same loop with the reference's "
+                         "10-block x 128 network shape (SURVEY.md 8d)")
     a = ap.parse_args()
     import numpy as np
     import torch
     assert torch.cuda.is_available()
     from elf_amd.net import PolicyValueNet, random_state_dict
     from tests import _gcwrapper      # the 60-line GCWrapper stand-in (createSharedMemOptions / AnyP.set / wait / step)
-    import _elfgames_go as gomod
-    cfg = dict(planes=18, board=19, dim=32, num_block=2, num_action=362)
+    import importlib
+    gomod = importlib.import_module({"go": "_elfgames_go", "american": "_elfgames_american_checkers",
+                                     "russian": "_elfgames_russian_checkers", "ugolki": "_elfgames_ugolki"}[a.game])
+    cfg = {"go": dict(planes=18, board=19, dim=32, num_block=2, num_action=362),
+           "american": dict(planes=36, board=8, dim=128, num_block=10, num_action=170),
+           "russian": dict(planes=6, board=8, dim=128, num_block=10, num_action=280),
+           "ugolki": dict(planes=16, board=8, dim=128, num_block=10, num_action=418)}[a.game]
     net = PolicyValueNet(max_batch=a.batchsize, **cfg)
     net.load_state_dict(random_state_dict(seed=0, **cfg))
     co = gomod.ContextOptions()
@@ -71,25 +79,27 @@ def main():
         th = threading.Thread(target=warm, daemon=True)
         th.start()
 
-    def ply():
-        return (GC.getGame(0).getStateWords()[20] >> 16) & 0xFFFF
+    def done():                 # moves made = searches finished (games that end restart, so plies do not count them)
+        return GC.searchStats()["rollouts"] // (a.games * a.rollouts)
 
-    while ply() < 2:            # warm-up: two moves
+    while done() < 2:           # warm-up: two moves
         w.run()
     rows[0] = 0; t_model[0] = 0.0
     s0 = GC.searchStats()
-    p0 = ply()
+    p0 = done()
     t0 = time.perf_counter()
-    while ply() < p0 + a.moves:
+    while done() < p0 + a.moves:
         w.run()
     dt = time.perf_counter() - t0
     s1 = GC.searchStats()
     evals = s1["evals"] - s0["evals"]
-    print(json.dumps({"metric": "go_nn_evaluated_mcts_rollouts_per_sec", "value": evals / dt, "unit": "rollouts/s", "n_gpus": 1,
-                      "dtype": "bf16", "data": "synthetic",
-                      "config": {"workload": "Go 19x19 self-play through _elfgames_go GameContext wait/step, %d games, %d rollouts/move, "
-                                             "%d leaves/batch, 2-block x 32 ResNet as a Python actor (BASELINE.json configs[0])"
-                                             % (a.games, a.rollouts, a.leaves), "batchsize": a.batchsize, "moves_timed": a.moves},
+    what = ("Go 19x19 self-play through _elfgames_go GameContext wait/step, %d games, %d rollouts/move, %d leaves/batch, "
+            "2-block x 32 ResNet as a Python actor (BASELINE.json configs[0])" if a.game == "go" else
+            a.game + " self-play through " + gomod.__name__ + " GameContext wait/step, %d games, %d rollouts/move, %d leaves/batch, "
+            "10-block x 128 ResNet as a Python actor") % (a.games, a.rollouts, a.leaves)
+    print(json.dumps({"metric": ("go" if a.game == "go" else a.game) + "_nn_evaluated_mcts_rollouts_per_sec", "value": evals / dt,
+                      "unit": "rollouts/s", "n_gpus": 1, "dtype": "bf16", "data": "synthetic",
+                      "config": {"workload": what, "batchsize": a.batchsize, "moves_timed": a.moves},
                       "rows_served": rows[0], "rollouts_all_per_sec": (s1["rollouts"] - s0["rollouts"]) / dt,
                       "seconds": dt, "seconds_in_python_actor": t_model[0], "host_ms": {k: round(s1["host_ms"][k] - s0["host_ms"][k], 1) for k in s1["host_ms"]}}), flush=True)
     w.stop()
