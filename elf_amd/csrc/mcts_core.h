@@ -186,6 +186,7 @@ struct ExpandScratch {
   stdorder::Item items[NA + 2];
   stdorder::Item sorted[NA];   // rank-sort output (distinct keys); with ties the serial emulation sorts items in place
   uint16_t keys[MAXLEGAL]; float pri[MAXLEGAL];
+  __attribute__((aligned(16))) float kbuf[(NA + 3) & ~3];   // the priors alone, for the rank sort's float4 reads
   // scratch of stdorder::umap_iteration_order_wave
   __attribute__((aligned(16))) int rkey[(MAXLEGAL + 3) & ~3];
   int table[MAXLEGAL <= 59 ? 64 : MAXLEGAL <= 127 ? 128 : 544];
@@ -203,41 +204,47 @@ struct ExpandScratch {
 template <int NA, int MAXLEGAL>
 __device__ inline int expand_prepare(const TreeDev& d, const uint64_t* mk, const float* __restrict__ pi, int lane,
                                      ExpandScratch<NA, MAXLEGAL>& S) {
-  if (pi) {
-    for (int i = lane; i < NA; i += 64) { S.items[i].key = pi[i]; S.items[i].idx = (uint16_t)i; }
-  } else {
-    for (int i = lane; i < NA; i += 64) { S.items[i].key = 1.0f / (float)NA; S.items[i].idx = d.uniform_order[i]; }
-  }
-  stdorder::wave_sync();
   // std::sort descending by pi (MCTSGameActor.h:295-300).  With distinct keys the result is THE descending
-  // order whatever the algorithm, so the wave rank-sorts in parallel (rank = number of larger keys, every lane
-  // scans all NA keys as LDS broadcasts).  std::sort is not stable: only when two keys are equal (or a key is
-  // NaN) does the order depend on libstdc++'s introsort, and then lane 0 runs its exact emulation as before
-  // (a single lane's dependent LDS round trips made that ~0.5 ms per Go leaf).
+  // order whatever the algorithm, so the wave rank-sorts in parallel: an item's place is the number of larger
+  // keys (every lane scans all keys, four per LDS broadcast).  std::sort is not stable: only when two keys are
+  // equal (or a key is NaN) does the order depend on libstdc++'s introsort, and then lane 0 runs its exact
+  // emulation (a single lane's dependent LDS round trips: ~0.5 ms per Go leaf).  Equal keys get equal ranks, so a
+  // tie shows as a place nobody wrote.
   const stdorder::Item* sorted = S.items;
   if (pi) {
+    constexpr int NA4 = (NA + 3) & ~3;
+    for (int i = lane; i < NA4; i += 64) {
+      S.kbuf[i] = i < NA ? pi[i] : -__builtin_inff();
+      if (i < NA) S.sorted[i].idx = 0xFFFF;
+    }
+    stdorder::wave_sync();
     bool odd = false;
     for (int c = 0; c < NA; c += 64) {
       const int i = c + lane;
       const bool in = i < NA;
-      const float ki = S.items[in ? i : 0].key;
-      int rank = 0, same = 0;
-      for (int j = 0; j < NA; ++j) {
-        const float kj = S.items[j].key;
-        rank += kj > ki ? 1 : 0;
-        same += kj == ki ? 1 : 0;
+      const float ki = S.kbuf[in ? i : 0];
+      int rank = 0;
+      for (int j = 0; j < NA4; j += 4) {
+        const float4 k = *(const float4*)(S.kbuf + j);
+        rank += (k.x > ki ? 1 : 0) + (k.y > ki ? 1 : 0) + (k.z > ki ? 1 : 0) + (k.w > ki ? 1 : 0);
       }
       if (in) {
-        if (same != 1) odd = true;
-        else S.sorted[rank] = S.items[i];
+        if (ki != ki) odd = true;
+        else { stdorder::Item it; it.key = ki; it.idx = (uint16_t)i; S.sorted[rank] = it; }
       }
     }
+    stdorder::wave_sync();
+    for (int i = lane; i < NA; i += 64) odd |= S.sorted[i].idx == 0xFFFF;
     if (__any(odd)) {
+      for (int i = lane; i < NA; i += 64) { S.items[i].key = S.kbuf[i]; S.items[i].idx = (uint16_t)i; }
       stdorder::wave_sync();
       if (lane == 0) stdorder::sort_desc(S.items, NA);
     } else {
       sorted = S.sorted;
     }
+    stdorder::wave_sync();
+  } else {
+    for (int i = lane; i < NA; i += 64) { S.items[i].key = 1.0f / (float)NA; S.items[i].idx = d.uniform_order[i]; }
     stdorder::wave_sync();
   }
   // checkMove filter (:305-331): the legal items keep their sorted order.  Lanes test 64 items at a
