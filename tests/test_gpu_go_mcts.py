@@ -128,6 +128,40 @@ def test_go_backup_shapes_give_the_same_trees(torch_cuda, waves, monkeypatch):
           policy_kind=1, seed=17, start_plies=50, max_nodes=512, max_edges=160000)
 
 
+def test_go_batch_of_sixteen_leaves(torch_cuda):
+    """num_rollouts_per_batch = 16 (the limit): the backup kernel takes the leaves in two rounds of eight waves."""
+    _play(torch_cuda, 4, 2, dict(num_rollouts_per_thread=64, num_rollouts_per_batch=16, virtual_loss=1, c_puct=1.5),
+          policy_kind=1, seed=23, start_plies=45, max_nodes=512, max_edges=160000)
+
+
+@pytest.mark.parametrize("waves", [1, 8])
+def test_go_edge_arena_overflow_parks_the_tree(torch_cuda, waves, monkeypatch):
+    """An edge arena too small for the search: the tree is flagged (FLAG_EDGE_OVERFLOW = 2) and left alone by later
+    launches instead of writing past its arena; a neighbour slab allocated right after the trees stays intact."""
+    from elf_amd.boards import GO19
+    from elf_amd.mcts import TreeSearchBatch
+    monkeypatch.setenv("ELFHIP_GO_BACKUP_WAVES", str(waves))
+    n = 4
+    games, bb = _open_games(torch_cuda, n, 20, seed=31)
+    ts = TreeSearchBatch(GO19, n, num_rollouts_per_thread=32, num_rollouts_per_batch=8, virtual_loss=1, c_puct=1.5,
+                         max_nodes=128, max_edges=1000)      # root (~340 edges) + two children fit, the fourth node does not
+    guard = torch_cuda.full((1 << 20,), 0x5A, dtype=torch_cuda.uint8, device="cuda")
+    assert ts.set_roots(bb).cpu().numpy().all()
+
+    def evaluator(feat, states, need):
+        pi = torch_cuda.rand((n * 8, 362), device="cuda") + 0.01
+        return pi / pi.sum(1, keepdim=True), torch_cuda.zeros(n * 8, device="cuda")
+
+    ts.run(evaluator)
+    flags = ts.stats()[1].cpu().numpy()
+    assert (flags & 2).all(), flags
+    res = _cpu(ts.result(edge_cap=362, with_policy=True))
+    assert (res["total_visits"] >= 0).all()
+    ts.run(evaluator)                                       # parked trees: the launches skip them
+    assert np.array_equal(ts.stats()[1].cpu().numpy(), flags)
+    assert bool((guard == 0x5A).all())
+
+
 def test_go_late_game_captures_ko_and_passes(torch_cuda):
     """Crowded boards: captures, ko and suicide exclusions inside the tree; pass edges get visited
     so two-pass terminal leaves (Tromp-Taylor value) occur."""
