@@ -632,14 +632,14 @@ net_heads_kernel(const T* __restrict__ x, int H, int W, int C, int A,
   __syncthreads();
   for (int a = tid; a < A; a += 256) {
     float acc = pl_b[a];
-    const float* wr = pl_w + (size_t)a * HW;
-    for (int p = 0; p < HW; ++p) acc += wr[p] * fpi[p];
+    const float* wr = pl_w + a;                       // pl_w is [HW][A]: the same sum in the same order, coalesced
+    for (int p = 0; p < HW; ++p) acc += wr[(size_t)p * A] * fpi[p];
     logits[a] = acc;
   }
   {
     float acc = v1_b[tid];
-    const float* wr = v1_w + (size_t)tid * HW;
-    for (int p = 0; p < HW; ++p) acc += wr[p] * fv[p];
+    const float* wr = v1_w + tid;                     // [HW][256]
+    for (int p = 0; p < HW; ++p) acc += wr[(size_t)p * 256] * fv[p];
     hid[tid] = fmaxf(acc, 0.f);
   }
   __syncthreads();
@@ -818,9 +818,17 @@ struct NetImpl {
     };
     int rc = head1x1(wpi, bpi); if (rc) return rc;
     rc = head1x1(wv, bv); if (rc) return rc;
-    HIPCHECK(hipMemcpy(pl_w, p, cfg.num_action * hw * 4, hipMemcpyHostToDevice)); p += cfg.num_action * hw;
+    {  // stored transposed ([point][action]): the heads kernel's lanes are actions, so a wave reads one contiguous row
+      std::vector<float> t((size_t)cfg.num_action * hw);
+      for (int a = 0; a < cfg.num_action; ++a) for (int q = 0; q < hw; ++q) t[(size_t)q * cfg.num_action + a] = p[(size_t)a * hw + q];
+      HIPCHECK(hipMemcpy(pl_w, t.data(), t.size() * 4, hipMemcpyHostToDevice)); p += cfg.num_action * hw;
+    }
     HIPCHECK(hipMemcpy(pl_b, p, cfg.num_action * 4, hipMemcpyHostToDevice)); p += cfg.num_action;
-    HIPCHECK(hipMemcpy(v1_w, p, 256 * hw * 4, hipMemcpyHostToDevice)); p += 256 * hw;
+    {  // likewise [point][hidden unit]
+      std::vector<float> t((size_t)256 * hw);
+      for (int a = 0; a < 256; ++a) for (int q = 0; q < hw; ++q) t[(size_t)q * 256 + a] = p[(size_t)a * hw + q];
+      HIPCHECK(hipMemcpy(v1_w, t.data(), t.size() * 4, hipMemcpyHostToDevice)); p += 256 * hw;
+    }
     HIPCHECK(hipMemcpy(v1_b, p, 256 * 4, hipMemcpyHostToDevice)); p += 256;
     HIPCHECK(hipMemcpy(v2_w, p, 256 * 4, hipMemcpyHostToDevice)); p += 256;
     v2_b = *p++;
