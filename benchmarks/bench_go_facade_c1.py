@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--leaves", type=int, default=8)
     ap.add_argument("--batchsize", type=int, default=512)
     ap.add_argument("--moves", type=int, default=8)
+    ap.add_argument("--device-batches", action="store_true",
+                    help="bind s / pi / V to GPU tensors (AnyP.set with device pointers): the batch stays in HBM; the "
+                         "reference's interface (pinned host tensors) is the default")
     ap.add_argument("--game", default="go", choices=["go", "american", "russian", "ugolki"],
                     help="go = BASELINE.json configs[0]; the checkers-family modules run the same loop with the reference's "
                          "10-block x 128 network shape (SURVEY.md 8d)")
@@ -48,14 +51,18 @@ def main():
     go.mode, go.policy_distri_cutoff = "selfplay", 0
     GC = gomod.GameContext(co, go)
     desc = dict(game_end=dict(batchsize=1), actor_black=dict(input=["s"], reply=["pi", "V", "a", "rv"], batchsize=a.batchsize))
-    w = _gcwrapper.Wrapper(GC, a.batchsize, desc, num_recv=2)
+    w = _gcwrapper.Wrapper(GC, a.batchsize, desc, num_recv=2, device_keys=("s", "pi", "V") if a.device_batches else ())
     t_model = [0.0]
     rows = [0]
 
     def actor(batch, bs):
         t0 = time.perf_counter()
-        out = net.forward(torch.from_numpy(batch["s"]).cuda())
-        pi, v = out["pi"].cpu().numpy(), out["V"].cpu().numpy().reshape(-1)
+        if a.device_batches:
+            out = net.forward(batch["s"])
+            pi, v = out["pi"], out["V"].reshape(-1)
+        else:
+            out = net.forward(torch.from_numpy(batch["s"]).cuda())
+            pi, v = out["pi"].cpu().numpy(), out["V"].cpu().numpy().reshape(-1)
         t_model[0] += time.perf_counter() - t0
         rows[0] += bs
         return dict(pi=pi, V=v, a=np.zeros(bs, dtype=np.int64), rv=np.zeros(bs, dtype=np.int64))
@@ -99,7 +106,8 @@ def main():
             "10-block x 128 ResNet as a Python actor") % (a.games, a.rollouts, a.leaves)
     print(json.dumps({"metric": ("go" if a.game == "go" else a.game) + "_nn_evaluated_mcts_rollouts_per_sec", "value": evals / dt,
                       "unit": "rollouts/s", "n_gpus": 1, "dtype": "bf16", "data": "synthetic",
-                      "config": {"workload": what, "batchsize": a.batchsize, "moves_timed": a.moves},
+                      "config": {"workload": what, "batchsize": a.batchsize, "moves_timed": a.moves,
+                                 "batches": "GPU tensors bound by device pointer" if a.device_batches else "host arrays (the reference's interface)"},
                       "rows_served": rows[0], "rollouts_all_per_sec": (s1["rollouts"] - s0["rollouts"]) / dt,
                       "seconds": dt, "seconds_in_python_actor": t_model[0], "host_ms": {k: round(s1["host_ms"][k] - s0["host_ms"][k], 1) for k in s1["host_ms"]}}), flush=True)
     w.stop()

@@ -527,15 +527,16 @@ class SelfPlayEngine : public elfhip_py::Engine {
           else (void)hipGetLastError();
         }
   }
-  // rows [0,k) of a caller's array <-> a dense device buffer
+  // rows [0,k) of a caller's array <-> a dense device buffer.  The caller's array may itself live on the GPU
+  // (AnyP.set with a device pointer: the batch then never crosses PCIe); the copy kind is left to the runtime.
   void copy_rows(void* dev, const AnyP* a, size_t row_bytes, int k, bool to_device, const char* what) {
     const size_t stride = (size_t)a->strides.at(0);
     if (stride == row_bytes || k == 1) {
-      hk(to_device ? hipMemcpy(dev, a->row(0), row_bytes * (size_t)k, hipMemcpyHostToDevice)
-                   : hipMemcpy(a->row(0), dev, row_bytes * (size_t)k, hipMemcpyDeviceToHost), what);
+      hk(to_device ? hipMemcpy(dev, a->row(0), row_bytes * (size_t)k, hipMemcpyDefault)
+                   : hipMemcpy(a->row(0), dev, row_bytes * (size_t)k, hipMemcpyDefault), what);
     } else {
-      hk(to_device ? hipMemcpy2D(dev, row_bytes, a->row(0), stride, row_bytes, (size_t)k, hipMemcpyHostToDevice)
-                   : hipMemcpy2D(a->row(0), stride, dev, row_bytes, row_bytes, (size_t)k, hipMemcpyDeviceToHost), what);
+      hk(to_device ? hipMemcpy2D(dev, row_bytes, a->row(0), stride, row_bytes, (size_t)k, hipMemcpyDefault)
+                   : hipMemcpy2D(a->row(0), stride, dev, row_bytes, row_bytes, (size_t)k, hipMemcpyDefault), what);
     }
   }
   void release() {

@@ -15,7 +15,9 @@ NP_TYPES = {"int32_t": "i4", "int64_t": "i8", "float": "f4", "unsigned char": "u
 
 
 class Wrapper:
-    def __init__(self, GC, batchsize, desc, num_recv=2):
+    def __init__(self, GC, batchsize, desc, num_recv=2, device_keys=()):
+        """device_keys: keys whose arrays are torch CUDA tensors bound by device pointer (no reference counterpart: the
+        reference's batches are pinned host tensors; here a GPU-side actor can read / write them in place)."""
         self.GC, self.ctx = GC, GC.ctx()
         self.batches, self.name2idx, self.idx2name, self.cb = {}, {}, {}, {}
         for name, v in desc.items():
@@ -28,8 +30,13 @@ class Wrapper:
                 for k in set(keys_in + keys_rep):
                     p = smem[k]
                     f = p.field()
-                    a = np.ones(f.sz().vec(), dtype=NP_TYPES[f.type_name()])
-                    p.set(a.ctypes.data, list(a.strides))
+                    if k in device_keys:
+                        import torch
+                        a = torch.ones(f.sz().vec(), dtype=getattr(torch, {"f4": "float32", "i4": "int32", "i8": "int64", "u1": "uint8"}[NP_TYPES[f.type_name()]]), device="cuda")
+                        p.set(a.data_ptr(), [st * a.element_size() for st in a.stride()])
+                    else:
+                        a = np.ones(f.sz().vec(), dtype=NP_TYPES[f.type_name()])
+                        p.set(a.ctypes.data, list(a.strides))
                     arrs[k] = a
                 idx = smem.getSharedMemOptions().idx()
                 self.batches[idx] = dict(input={k: arrs[k] for k in keys_in}, reply={k: arrs[k] for k in keys_rep})
@@ -53,7 +60,12 @@ class Wrapper:
         if isinstance(reply, dict):
             assert set(reply) == set(self.batches[idx]["reply"])
             for k, v in reply.items():
-                self.batches[idx]["reply"][k][:bs] = v
+                dst = self.batches[idx]["reply"][k]
+                if isinstance(dst, np.ndarray):
+                    dst[:bs] = v
+                else:
+                    import torch
+                    dst[:bs] = torch.as_tensor(v, device=dst.device).reshape(dst[:bs].shape)
         self.ctx.step()
         return self.idx2name[idx], bs
 

@@ -12,7 +12,7 @@ from tests.test_gpu_selfplay import _oracle_game
 pytestmark = pytest.mark.gpu
 
 
-def _context(n_games, batchsize, rollouts, rpb, cutoff=0, two_models=False):
+def _context(n_games, batchsize, rollouts, rpb, cutoff=0, two_models=False, device_keys=()):
     import _elfgames_american_checkers as ac
     co = ac.ContextOptions()
     co.num_games, co.batchsize = n_games, batchsize
@@ -25,7 +25,7 @@ def _context(n_games, batchsize, rollouts, rpb, cutoff=0, two_models=False):
     desc = dict(game_end=dict(batchsize=1),
                 actor_white=dict(input=["s"], reply=["pi", "V", "a", "rv"], batchsize=batchsize),
                 actor_black=dict(input=["s"], reply=["pi", "V", "a", "rv"], batchsize=batchsize))
-    w = _gcwrapper.Wrapper(GC, batchsize, desc, num_recv=2)
+    w = _gcwrapper.Wrapper(GC, batchsize, desc, num_recv=2, device_keys=device_keys)
     if two_models:
         GC.getClient().setRequest(0, 1, 1)
     return GC, w
@@ -33,6 +33,8 @@ def _context(n_games, batchsize, rollouts, rpb, cutoff=0, two_models=False):
 
 def _uniform(batch, bs):
     s = batch["s"]
+    if not isinstance(s, np.ndarray):      # a batch bound to GPU tensors
+        s = s.cpu().numpy()
     assert s.shape == (bs, 36, 8, 8)
     assert np.isin(s, (0.0, 1.0)).all()
     assert (s[:, 34].reshape(bs, -1).max(1) + s[:, 35].reshape(bs, -1).max(1) == 1).all()   # side-to-move planes of the newest slot
@@ -40,10 +42,12 @@ def _uniform(batch, bs):
                 a=np.zeros(bs, dtype=np.int64), rv=np.zeros(bs, dtype=np.int64))
 
 
-@pytest.mark.parametrize("batchsize", [5, 64])
-def test_facade_selfplay_matches_oracle(batchsize):
+@pytest.mark.parametrize("batchsize,device_keys", [(5, ()), (64, ()), (7, ("s", "pi", "V"))])
+def test_facade_selfplay_matches_oracle(batchsize, device_keys):
+    """device_keys: the same games with s / pi / V bound to GPU tensors by device pointer (the batch never leaves
+    HBM) instead of the reference's host arrays."""
     n = 6
-    GC, w = _context(n, batchsize, rollouts=24, rpb=4)
+    GC, w = _context(n, batchsize, rollouts=24, rpb=4, device_keys=device_keys)
     counts = dict(actor_black=0, actor_white=0, game_end=0)
     ends = []
     w.reg_callback("actor_black", _uniform)
