@@ -69,22 +69,6 @@ def main():
 
     w.reg_callback("actor_black", actor)
     w.start()
-    if os.environ.get("ELF_BENCH_KEEP_WARM"):
-        # diagnostic only: a side stream of matrix products keeps the GPU's clocks up while the 64-tree loop leaves
-        # it nearly idle (the same run under rocprofv3 is several times faster)
-        import threading
-        stop = threading.Event()
-
-        def warm():
-            side = torch.cuda.Stream()
-            a_ = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
-            with torch.cuda.stream(side):
-                while not stop.is_set():
-                    for _ in range(4):
-                        a_ @ a_
-                    side.synchronize()
-        th = threading.Thread(target=warm, daemon=True)
-        th.start()
 
     def done():                 # moves made = searches finished (games that end restart, so plies do not count them)
         return GC.searchStats()["rollouts"] // (a.games * a.rollouts)
