@@ -11,8 +11,30 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]   # inline-asm: the LDS-DMA helper names m0 as clobbered
 
 
-def _newer(src, dst):
-    return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
+def _digest(paths, extra=""):
+    """sha256 over the named files' contents (sorted by path) and the command line."""
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in sorted(os.path.abspath(q) for q in paths):
+        h.update(p.encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(out, deps, cmd):
+    """True when `out` is missing or was built from other contents of `deps` / another command.  The digest lives
+    beside the output (`<out>.sha`), so a header edit anywhere in deps rebuilds whatever the mtimes say."""
+    want = _digest(deps, " ".join(cmd))
+    tag = out + ".sha"
+    if os.path.exists(out) and os.path.exists(tag) and open(tag).read().strip() == want:
+        return None
+    return want
+
+
+def _stamp(out, digest):
+    with open(out + ".sha", "w") as f:
+        f.write(digest + "\n")
 
 
 def build(force=False, verbose=False):
@@ -23,14 +45,16 @@ def build(force=False, verbose=False):
     for s in srcs:
         o = s[:-4] + ".o"
         objs.append(o)
-        if force or _newer(s, o) or any(_newer(h, o) for h in hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        dg = _stale(o, [s] + hdrs, cmd)
+        if force or dg:
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((s, subprocess.Popen(cmd)))
-    for s, p in procs:
+            procs.append((s, o, dg or _digest([s] + hdrs, " ".join(cmd)), subprocess.Popen(cmd)))
+    for s, o, dg, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % s)
+        _stamp(o, dg)
     if force or procs or not os.path.exists(LIB):
         cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
         if verbose:
@@ -47,13 +71,15 @@ def build_cpp_tests(force=False, verbose=False):
     hdrs = glob.glob(os.path.join(root, "include", "*"))
     for src in sorted(glob.glob(os.path.join(root, "tests", "cpp", "*.cc"))):
         out = src[:-3] + ".bin"
-        if force or _newer(src, out) or any(_newer(h, out) for h in hdrs):
-            cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                   "-I" + os.path.join(root, "include"), src, "-o", out, "-L" + HERE, "-lelfhip", "-L/opt/rocm/lib", "-lamdhip64",
-                   "-Wl,-rpath,$ORIGIN/../../elf_amd", "-Wl,-rpath,/opt/rocm/lib"]
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+               "-I" + os.path.join(root, "include"), src, "-o", out, "-L" + HERE, "-lelfhip", "-L/opt/rocm/lib", "-lamdhip64",
+               "-Wl,-rpath,$ORIGIN/../../elf_amd", "-Wl,-rpath,/opt/rocm/lib"]
+        dg = _stale(out, [src] + [h for h in hdrs if os.path.isfile(h)], cmd)
+        if force or dg:
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
+            _stamp(out, dg or _digest([src] + [h for h in hdrs if os.path.isfile(h)], " ".join(cmd)))
 
 
 # Python-visible facade modules with the reference's module names (host C++ only, g++):
@@ -78,14 +104,16 @@ def build_pybind(force=False, verbose=False):
     procs = []
     for name, src, defs, lk in jobs:
         out = os.path.join(PYB, name + suffix)
-        if force or _newer(src, out) or any(_newer(h, out) for h in hdrs):
-            cmd = base + defs + [src, "-o", out] + lk
+        cmd = base + defs + [src, "-o", out] + lk
+        dg = _stale(out, [src] + hdrs, cmd)
+        if force or dg:
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((name, subprocess.Popen(cmd)))
-    for name, p in procs:
+            procs.append((name, out, dg or _digest([src] + hdrs, " ".join(cmd)), subprocess.Popen(cmd)))
+    for name, out, dg, p in procs:
         if p.wait() != 0:
             raise RuntimeError("g++ failed on pybind module %s" % name)
+        _stamp(out, dg)
 
 
 if __name__ == "__main__":
