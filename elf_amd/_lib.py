@@ -17,7 +17,7 @@ F32, BF16, BITS = 0, 1, 2
 SYMBOLS = [
     "elfhip_last_error", "elfhip_device_count", "elfhip_abi_version", "elfhip_game_get_info",
     "elfhip_boards_create", "elfhip_boards_destroy", "elfhip_boards_set_stream", "elfhip_boards_count",
-    "elfhip_boards_game", "elfhip_boards_reset", "elfhip_boards_reset_mask", "elfhip_boards_export", "elfhip_boards_import",
+    "elfhip_boards_game", "elfhip_boards_reset", "elfhip_boards_reset_mask", "elfhip_boards_export", "elfhip_boards_export_static", "elfhip_boards_import",
     "elfhip_boards_legal_mask", "elfhip_boards_step", "elfhip_boards_features", "elfhip_boards_evaluate",
     "elfhip_boards_playout", "elfhip_test_sort_order", "elfhip_test_umap_order", "elfhip_test_umap_order_wave", "elfhip_gather_rows", "elfhip_scatter_rows",
     "elfhip_mcts_create", "elfhip_mcts_destroy", "elfhip_mcts_set_stream", "elfhip_mcts_clear", "elfhip_mcts_set_roots",
@@ -74,6 +74,7 @@ def lib():
     L.elfhip_boards_reset.argtypes = [vp]
     L.elfhip_boards_reset_mask.argtypes = [vp, vp]
     L.elfhip_boards_export.argtypes = [vp, vp]
+    L.elfhip_boards_export_static.argtypes = [vp, vp]
     L.elfhip_boards_import.argtypes = [vp, vp]
     L.elfhip_boards_legal_mask.argtypes = [vp, vp, vp]
     L.elfhip_boards_step.argtypes = [vp, vp, vp]

@@ -245,9 +245,13 @@ struct AmericanSlab : BoardSlab {
     HIPCHECK(hipGetLastError());
     return ELFHIP_OK;
   }
-  int export_states(uint64_t* h) override {
-    hipLaunchKernelGGL(am_export_kernel, dim3(grid()), dim3(256), 0, stream, w, aos, n);
+  int export_states_to(uint64_t* d_aos) override {
+    hipLaunchKernelGGL(am_export_kernel, dim3(grid()), dim3(256), 0, stream, w, d_aos, n);
     HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  int export_states(uint64_t* h) override {
+    if (int rc = export_states_to(aos)) return rc;
     HIPCHECK(hipMemcpyAsync(h, aos, sizeof(uint64_t) * 6 * (size_t)n, hipMemcpyDeviceToHost, stream));
     HIPCHECK(hipStreamSynchronize(stream));
     return ELFHIP_OK;

@@ -7,7 +7,34 @@
 #include "stdorder.h"
 #include <vector>
 
+#include <mutex>
+
 static thread_local char g_err[512] = "";
+
+// Staging area of elfhip_boards_export_static: lives in the code object, one copy per GPU, held until the process
+// ends.  In host code `scratch` is only a stand-in for hipGetSymbolAddress; everything else uses the per-device
+// address kept in g_scratch_ptr[].
+static __device__ __align__(256) unsigned char scratch[ELFHIP_EXPORT_STATIC_MAX_BYTES];
+static constexpr int kMaxDevices = 64;
+static void* g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mu;
+
+// address of `scratch` on `device` (which must be the current device); resolved once per device
+static int scratch_address(int device, void** out) {
+  if (device < 0 || device >= kMaxDevices) {
+    elfhip_set_error("export_static: device %d not in [0,%d)", device, kMaxDevices);
+    return ELFHIP_EINVAL;
+  }
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[device]) {
+    void* p = nullptr;
+    HIPCHECK(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+    if (!p) { elfhip_set_error("export_static: hipGetSymbolAddress returned null on device %d", device); return ELFHIP_EHIP; }
+    g_scratch_ptr[device] = p;
+  }
+  *out = g_scratch_ptr[device];
+  return ELFHIP_OK;
+}
 
 namespace {
 // row gather / scatter used by the batch collector: dst[i] = src[index[i]] (gather) or
@@ -156,6 +183,29 @@ int elfhip_boards_export(elfhip_boards* b, uint64_t* h_states) {
   CHECK_H(b);
   if (!h_states) { elfhip_set_error("boards_export: null buffer"); return ELFHIP_EINVAL; }
   return b->slab->export_states(h_states);
+}
+
+int elfhip_boards_export_static(elfhip_boards* b, uint64_t* h_states) {
+  CHECK_H(b);
+  if (!h_states) { elfhip_set_error("boards_export_static: null buffer"); return ELFHIP_EINVAL; }
+  elfhip_game_info gi;
+  if (int rc = elfhip_game_get_info(b->slab->game, &gi)) return rc;
+  const size_t bytes = sizeof(uint64_t) * (size_t)gi.state_words * (size_t)b->slab->n;
+  if (bytes > (size_t)ELFHIP_EXPORT_STATIC_MAX_BYTES) {
+    elfhip_set_error("boards_export_static: %d boards x %d words = %zu bytes exceed the static staging area of %d bytes "
+                     "(at most %d boards of this game); use elfhip_boards_export",
+                     b->slab->n, gi.state_words, bytes, ELFHIP_EXPORT_STATIC_MAX_BYTES,
+                     (int)(ELFHIP_EXPORT_STATIC_MAX_BYTES / (sizeof(uint64_t) * (size_t)gi.state_words)));
+    return ELFHIP_EINVAL;
+  }
+  void* stage = nullptr;
+  if (int rc = scratch_address(b->slab->device, &stage)) return rc;
+  // every word of rows [0, n) is written by the export kernel; rows beyond keep an earlier call's contents and are
+  // never read, so nothing has to start at zero
+  if (int rc = b->slab->export_states_to((uint64_t*)stage)) return rc;
+  HIPCHECK(hipMemcpyAsync(h_states, stage, bytes, hipMemcpyDeviceToHost, b->slab->stream));
+  HIPCHECK(hipStreamSynchronize(b->slab->stream));
+  return ELFHIP_OK;
 }
 
 int elfhip_boards_import(elfhip_boards* b, const uint64_t* h_states) {

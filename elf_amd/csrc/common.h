@@ -46,6 +46,8 @@ struct BoardSlab {
   virtual int reset() = 0;
   virtual int reset_mask(const uint8_t* d_which) = 0;  // reset only boards with d_which[i] != 0
   virtual int export_states(uint64_t* h) = 0;
+  // the export kernel alone: array-of-structs states into a DEVICE buffer of n*state_words u64 (enqueued, no sync)
+  virtual int export_states_to(uint64_t* d_aos) = 0;
   virtual int import_states(const uint64_t* h) = 0;
   virtual int legal_mask(uint64_t* d_mask, uint8_t* d_terminal) = 0;
   virtual int step(const int16_t* d_actions, uint8_t* d_ok) = 0;

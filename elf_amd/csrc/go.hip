@@ -293,9 +293,13 @@ struct GoSlab : BoardSlab {
     HIPCHECK(hipGetLastError());
     return ELFHIP_OK;
   }
-  int export_states(uint64_t* h) override {
-    hipLaunchKernelGGL(go_export_kernel, dim3(grid()), dim3(64), 0, stream, d, aos);
+  int export_states_to(uint64_t* d_aos) override {
+    hipLaunchKernelGGL(go_export_kernel, dim3(grid()), dim3(64), 0, stream, d, d_aos);
     HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  int export_states(uint64_t* h) override {
+    if (int rc = export_states_to(aos)) return rc;
     HIPCHECK(hipMemcpyAsync(h, aos, sizeof(uint64_t) * GO_WORDS * (size_t)n, hipMemcpyDeviceToHost, stream));
     HIPCHECK(hipStreamSynchronize(stream));
     return ELFHIP_OK;

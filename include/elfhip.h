@@ -88,6 +88,17 @@ int elfhip_boards_reset_mask(elfhip_boards* b, const uint8_t* d_which);
 int elfhip_boards_export(elfhip_boards* b, uint64_t* h_states);
 int elfhip_boards_import(elfhip_boards* b, const uint64_t* h_states);
 
+/* elfhip_boards_export for callers that cannot allocate.  No counterpart in the reference: it is for callers that
+ * must not trigger hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it).
+ * Same result as elfhip_boards_export, but the array-of-structs staging the export kernel writes is a file-scope
+ * __device__ array of ELFHIP_EXPORT_STATIC_MAX_BYTES (one copy per GPU, held until the process ends) instead of the
+ * handle's own buffer, and the call performs no hipMalloc / hipFree.  A slab with n_boards * state_words * 8 bytes
+ * beyond that size is rejected with ELFHIP_EINVAL (Go: at most 23,831 boards; American checkers: 87,381).
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two host threads, or two streams)
+ * race; serialise them.  Synchronises the handle's stream. */
+#define ELFHIP_EXPORT_STATIC_MAX_BYTES (4 << 20)
+int elfhip_boards_export_static(elfhip_boards* b, uint64_t* h_states);
+
 /* GetValidMovesBinary (GameBoard.cc:131-162) for every board: d_mask[n][mask_words] u64, bit a set
  * iff action a is legal.  d_terminal (nullable) [n] u8 receives GameState::terminated()
  * (GameState.h:51-53). */

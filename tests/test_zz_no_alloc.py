@@ -1,0 +1,54 @@
+"""elfhip_boards_export_static (the entry point that allocates nothing, include/elfhip.h) against
+elfhip_boards_export, through the C-ABI: bit-exact on two calls in a row, the second on a smaller slab, so the
+shared per-GPU staging array still holds the first call's rows beyond the second call's range."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from elf_amd import _lib
+from elf_amd.boards import BoardBatch, AMERICAN, RUSSIAN, UGOLKI, GO19
+
+pytestmark = pytest.mark.gpu
+
+MAX_BYTES = 4 << 20
+
+
+def _export_both(bb):
+    L = _lib.lib()
+    a = np.zeros((bb.n, bb.info.state_words), dtype=np.uint64)
+    b = np.full((bb.n, bb.info.state_words), 0xDEADBEEFDEADBEEF, dtype=np.uint64)
+    _lib.check(L.elfhip_boards_export(bb.h, a.ctypes.data_as(C.c_void_p)))
+    _lib.check(L.elfhip_boards_export_static(bb.h, b.ctypes.data_as(C.c_void_p)))
+    return a, b
+
+
+@pytest.mark.parametrize("game,n_big,n_small", [(GO19, 20000, 777), (AMERICAN, 65536, 1000), (RUSSIAN, 4096, 1), (UGOLKI, 3000, 2999)])
+def test_export_static_matches_export_twice(game, n_big, n_small):
+    big = BoardBatch(game, n_big)
+    big.playout(37, seed=0x5EED0001)
+    a, b = _export_both(big)
+    assert np.array_equal(a, b)
+    assert len({r.tobytes() for r in a[:256]}) > 1          # the playouts diverged: rows are not all alike
+    small = BoardBatch(game, n_small)
+    small.playout(11, seed=0x5EED0002, first_board_id=5)
+    a2, b2 = _export_both(small)
+    assert np.array_equal(a2, b2)
+    assert not np.array_equal(a2, a[:n_small])               # and it is not the first call's data
+    a3, b3 = _export_both(big)                               # back to the large slab: unchanged
+    assert np.array_equal(a3, a) and np.array_equal(b3, a)
+
+
+def test_export_static_rejects_slabs_beyond_the_static_area():
+    L = _lib.lib()
+    n = MAX_BYTES // (22 * 8) + 1                            # one Go board too many
+    bb = BoardBatch(GO19, n)
+    out = np.zeros((n, 22), dtype=np.uint64)
+    assert L.elfhip_boards_export_static(bb.h, out.ctypes.data_as(C.c_void_p)) == -1
+    assert b"exceed" in L.elfhip_last_error()
+    assert not out.any()
+    ok = BoardBatch(GO19, n - 1)                             # the largest slab that fits
+    a, b = _export_both(ok)
+    assert np.array_equal(a, b)
+    assert L.elfhip_boards_export_static(None, out.ctypes.data_as(C.c_void_p)) == -1
+    assert L.elfhip_boards_export_static(ok.h, None) == -1
