@@ -84,12 +84,8 @@ mcts_set_roots_kernel(TreeDev d, AmExtra x, int persistent, const uint64_t* __re
   const int t = blockIdx.x;
   if (threadIdx.x != 0) return;
   if (d.t_flags[t] & FLAG_INACTIVE) { if (ok) ok[t] = 1; return; }
-  if (!persistent) {
-    TV c = tree_view(d, t, 0);
-    init_node(c, 0, 0.f, -1, 0);
-    d.t_arena[t] = 0; d.t_nnodes[t] = 1; d.t_nedges[t] = 0; d.t_flags[t] &= ~FLAG_ROOT_MISMATCH;
-  }
-  TV tv = tree_view(d, t, d.t_arena[t]);
+  if (!persistent) { reset_tree(d, t); d.t_flags[t] &= ~FLAG_ROOT_MISMATCH; }
+  TV tv = tree_view(d, t);
   uint64_t b[6];
   for (int k = 0; k < 6; ++k) b[k] = w[(size_t)k * n + t];
   bool good = true;
@@ -165,7 +161,7 @@ mcts_search_kernel(TreeDev d, AmExtra x, Opt o, uint64_t* __restrict__ leaf_stat
   const int t = blockIdx.x, lane = threadIdx.x;
   int flags = d.t_flags[t];
   if (flags) return;  // overflowed / mismatched trees are parked until cleared
-  TV tv = tree_view(d, t, d.t_arena[t]);
+  TV tv = tree_view(d, t);
   int nn = d.t_nnodes[t], ne = d.t_nedges[t];
   unsigned long long rollouts = 0, evals = 0, depth_sum = 0, edge_sum = 0;
   const int nbatch = MODE == 0 ? (o.R + o.B - 1) / o.B : 1;
@@ -390,10 +386,7 @@ int elfhip_mcts_pick_policy_only(elfhip_mcts* h, const uint8_t* d_which, int16_t
 int elfhip_mcts_advance(elfhip_mcts* h, const int16_t* d_actions) {
   CHECK_M(h);
   if (!d_actions) { elfhip_set_error("mcts_advance: null actions"); return ELFHIP_EINVAL; }
-  mcts::MctsBase* m = h->m;
-  hipLaunchKernelGGL(mcts::mcts_advance_kernel, dim3(m->d.n_trees), dim3(64), (size_t)m->d.max_nodes * 2, m->stream, m->d, d_actions);
-  HIPCHECK(hipGetLastError());
-  return ELFHIP_OK;
+  return h->m->advance(d_actions);
 }
 
 int elfhip_mcts_stats(elfhip_mcts* h, unsigned long long* h_stats4, int32_t* d_flags) {

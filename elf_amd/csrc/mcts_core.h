@@ -7,6 +7,7 @@
 // Reference: elf/ai/tree_search/tree_search.h:241-378, tree_search_node.h:188-317,385-421,458-507,
 // tree_search_base.h:175-201,310-367, elfgames/american_checkers/mcts/MCTSGameActor.h:198-335.
 #pragma once
+#include <stdlib.h>
 #include <cmath>
 #include <new>
 #include <random>
@@ -28,12 +29,21 @@ struct Opt {
   int R, B, vl, use_prior; float c_puct; int uqz, ruqz, persistent, pick;
 };
 
-// Node and edge records are arrays of structures: a descent step reads ONE 32-byte node header and the
-// node's contiguous 24-byte edge records, and the backup writes back into the same lines.  (With one
-// array per field a node visit touched ~11 different cache lines and a rollout wrote ~50; the checkers
-// search moved 10x its algorithmic bytes through HBM, most of it partial-line write-backs.)
-constexpr int NODE_BYTES = 32;  // meta 0, ebase 4, visits 8, V 12, meanQ 16, parentQ 20, parent 24, paction 28
-constexpr int EDGE_BYTES = 24;  // prior 0, child 4, reward 8, visits 12, vloss 16, action 20
+// Node and edge records are arrays of structures.  A node record is one 64-byte line:
+//   q0 {meta, ebase, numVisits, V}  q1 {meanQ, parentQ, parent, parent action}
+//   q2 {reward, num_visits, virtual_loss of the edge that LEADS to this node}  q3 spare
+// and an edge is 8 bytes {prior f32, action u16, child u16 (NOCHILD = none)}: the statistics of an edge
+// (EdgeInfo::reward / num_visits / virtual_loss, tree_search_base.h:137-159) exist only once the edge has been
+// followed, i.e. exactly when its child node exists, so they live in the child's record.  A Go node with ~320
+// edges costs 2.6 KB instead of 7.7 KB, the backup touches node records only (no edge line is written after
+// setEvaluation), and an unvisited edge reads as (0, 0, 0) without a memory access.
+// Trees do not own two ping-pong arenas: there is ONE pool of n_trees + n_spare arenas, t_arena[t] names the
+// arena tree t lives in, and treeAdvance compacts chunk after chunk of n_spare trees into the spare arenas, which
+// then swap roles with the arenas they replaced.
+constexpr int NODE_BYTES = 64;
+constexpr int EDGE_BYTES = 8;   // prior 0, action 4, child 6
+constexpr int NOCHILD = 0xFFFF;
+constexpr int MAX_NODES_LIMIT = 30000;  // u16 node ids (NOCHILD excluded); the advance kernel maps them in LDS
 template <class T, int STRIDE>
 struct Field {  // field of record i; indexes like the plain array it replaces
   char* p;
@@ -42,43 +52,59 @@ struct Field {  // field of record i; indexes like the plain array it replaces
 
 struct TreeDev {
   int n_trees, max_nodes, max_edges, state_words;  // state_words: u32 words of game state per node
-  char* n_rec;        // node headers [2][n_trees][max_nodes] x NODE_BYTES
-  uint32_t* n_state;  // game state per node [2][n_trees][max_nodes][state_words]
-  char* e_rec;        // edges [2][n_trees][max_edges] x EDGE_BYTES
+  int n_arenas, n_spare;                           // arena pool: n_trees + n_spare
+  char* n_rec;        // node records [n_arenas][max_nodes] x NODE_BYTES
+  uint32_t* n_state;  // game state per node [n_arenas][max_nodes][state_words]
+  char* e_rec;        // edges [n_arenas][max_edges] x EDGE_BYTES
   // per tree
   int32_t* t_arena; int32_t* t_nnodes; int32_t* t_nedges; int32_t* t_flags;
+  int32_t* spare_arena;  // [n_spare] arenas no tree lives in (treeAdvance's destinations)
   // batch scratch
-  uint16_t* traj_node; uint16_t* traj_edge;  // [n_trees][B][MAXD]
+  uint16_t* traj_node;  // [n_trees][B][MAXD]
   int32_t* traj_len; int32_t* leaf; uint8_t* locked;  // [n_trees][B]
   const uint16_t* uniform_order;  // std::sort order of num_actions equal keys
   unsigned long long* stats;      // rollouts, evals, depth_sum, edge_sum
 };
 
-struct TV {  // one tree, one arena
+struct TV {  // one tree in its arena
   Field<uint32_t, NODE_BYTES> meta, ebase; Field<int32_t, NODE_BYTES> visits; Field<float, NODE_BYTES> V, meanQ, parentQ;
   Field<int32_t, NODE_BYTES> parent; Field<uint16_t, NODE_BYTES> paction;
+  Field<float, NODE_BYTES> in_r; Field<int32_t, NODE_BYTES> in_n; Field<float, NODE_BYTES> in_l;  // incoming edge statistics
   uint32_t* state;
-  Field<uint16_t, EDGE_BYTES> ea; Field<float, EDGE_BYTES> ep; Field<int32_t, EDGE_BYTES> ec; Field<float, EDGE_BYTES> er;
-  Field<int32_t, EDGE_BYTES> ev; Field<float, EDGE_BYTES> el;
+  Field<float, EDGE_BYTES> ep; Field<uint16_t, EDGE_BYTES> ea, ec;
 };
 
-__device__ inline TV tree_view(const TreeDev& d, int t, int arena) {
-  size_t nb = ((size_t)arena * d.n_trees + t) * d.max_nodes, eb = ((size_t)arena * d.n_trees + t) * d.max_edges;
+__device__ inline TV arena_view(const TreeDev& d, int arena) {
+  size_t nb = (size_t)arena * d.max_nodes, eb = (size_t)arena * d.max_edges;
   TV v;
   char* nr = d.n_rec + nb * NODE_BYTES;
   char* er = d.e_rec + eb * EDGE_BYTES;
   v.meta.p = nr; v.ebase.p = nr + 4; v.visits.p = nr + 8; v.V.p = nr + 12;
   v.meanQ.p = nr + 16; v.parentQ.p = nr + 20; v.parent.p = nr + 24; v.paction.p = nr + 28;
+  v.in_r.p = nr + 32; v.in_n.p = nr + 36; v.in_l.p = nr + 40;
   v.state = d.n_state + nb * d.state_words;
-  v.ep.p = er; v.ec.p = er + 4; v.er.p = er + 8; v.ev.p = er + 12; v.el.p = er + 16; v.ea.p = er + 20;
+  v.ep.p = er; v.ea.p = er + 4; v.ec.p = er + 6;
   return v;
 }
+__device__ inline TV tree_view(const TreeDev& d, int t) { return arena_view(d, d.t_arena[t]); }
 
 __device__ inline void init_node(TV& tv, int id, float pq, int parent, int paction) {  // NodeT ctor tree_search_node.h:110-115
-  // the 32-byte header as two 16-byte stores: {meta = NOT_VISITED, ebase 0, visits 0, V 0} {meanQ, parentQ, parent, paction}
+  // {meta = NOT_VISITED, ebase 0, visits 0, V 0} {meanQ, parentQ, parent, paction} {EdgeInfo ctor: reward 0, num_visits 0, virtual_loss 0}
   char* r = tv.meta.p + (size_t)id * NODE_BYTES;
   *(uint4*)r = make_uint4(NOT_VISITED, 0u, 0u, 0u);
   *(uint4*)(r + 16) = make_uint4(__float_as_uint(pq), __float_as_uint(pq), (uint32_t)parent, (uint32_t)(uint16_t)paction);
+  *(uint4*)(r + 32) = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// EdgeInfo::num_visits / reward of edge e (0 until the edge has been followed)
+__device__ inline int edge_visits(const TV& tv, int e) { const int c = tv.ec[e]; return c == NOCHILD ? 0 : tv.in_n[c]; }
+__device__ inline float edge_reward(const TV& tv, int e) { const int c = tv.ec[e]; return c == NOCHILD ? 0.f : tv.in_r[c]; }
+
+// MCTSAI_T::resetTree: an empty tree (one unvisited root) in the arena the tree already owns
+__device__ inline void reset_tree(const TreeDev& d, int t) {
+  TV tv = tree_view(d, t);
+  init_node(tv, 0, 0.f, -1, 0);
+  d.t_nnodes[t] = 1; d.t_nedges[t] = 0;
 }
 
 // One descent from the root (single_rollout tree_search.h:319-378).  Wave-uniform; returns the leaf.
@@ -90,10 +116,9 @@ template <class Game>
 __device__ inline int select_one(const TreeDev& d, TV& tv, const Opt& o, int t, int slot, int lane, int& nn, int& flags,
                                  int& depth_out) {
   uint16_t* tn = d.traj_node + ((size_t)t * o.B + slot) * MAXD;
-  uint16_t* te = d.traj_edge + ((size_t)t * o.B + slot) * MAXD;
   int node = 0, depth = 0;
   for (;;) {
-    // the whole 32-byte header in two 16-byte loads issued together: one memory round trip per level
+    // q0 and q1 of the record in two 16-byte loads issued together: one memory round trip per level
     const uint4 h0 = *(const uint4*)(tv.meta.p + (size_t)node * NODE_BYTES);        // meta, ebase, visits, V
     const uint4 h1 = *(const uint4*)(tv.meta.p + (size_t)node * NODE_BYTES + 16);   // meanQ, parentQ, parent, paction
     const uint32_t meta = h0.x;
@@ -108,18 +133,22 @@ __device__ inline int select_one(const TreeDev& d, TV& tv, const Opt& o, int t, 
     const float pq = __uint_as_float(h1.y);
     const int nv = (int)h0.z;
     const double sq = sqrt((double)(nv + 1));
-    float best = -INFINITY; int bestj = 0x7FFFFFFF, bestc = -1;
+    float best = -INFINITY; int bestj = 0x7FFFFFFF, bestc = NOCHILD;
     float bestvl = 0.f;   // the chosen edge's virtual loss, kept from the scan (no reload before the update)
     float total_uq = 0.f; int total_cnt = 0;
     for (int base = 0; base < ne; base += 64) {
       const int j = base + lane;
       const bool ok = j < ne;
-      float score = -INFINITY, uq = 0.f, vloss = 0.f; int counted = 0, cj = -1;
+      float score = -INFINITY, uq = 0.f, vloss = 0.f; int counted = 0, cj = NOCHILD;
       if (ok) {  // EdgeInfo::getScore tree_search_base.h:175-201
-        const float prior = tv.ep[eb + j], reward = tv.er[eb + j];
-        vloss = tv.el[eb + j];
-        const int visits = tv.ev[eb + j];
-        cj = tv.ec[eb + j];  // fetched with the other edge fields: saves a dependent round trip after the argmax
+        const uint2 e = *(const uint2*)(tv.ep.p + (size_t)(eb + j) * EDGE_BYTES);   // {prior, action | child << 16}
+        const float prior = __uint_as_float(e.x);
+        cj = (int)(e.y >> 16);
+        float reward = 0.f; int visits = 0;   // an edge never followed: EdgeInfo's constructor values
+        if (cj != NOCHILD) {
+          const uint4 st = *(const uint4*)(tv.in_r.p + (size_t)cj * NODE_BYTES);    // {reward, num_visits, virtual_loss}
+          reward = __uint_as_float(st.x); visits = (int)st.y; vloss = __uint_as_float(st.z);
+        }
         float r = flip ? -reward : reward;
         r -= vloss;
         const int nvl = (int)((float)visits + vloss);
@@ -141,8 +170,10 @@ __device__ inline int select_one(const TreeDev& d, TV& tv, const Opt& o, int t, 
         bestc = __builtin_amdgcn_readlane(cj, bestj == 0x7FFFFFFF ? 0 : bestj);
         bestvl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vloss), bestj == 0x7FFFFFFF ? 0 : bestj));
       } else {
-        // first strict maximum in edge order == max score, lowest index on ties
-        float s = score, sv = vloss; int sj = ok ? j : 0x7FFFFFFF, sc = cj;
+        // first strict maximum in edge order == max score, lowest index on ties.  A NaN score (NaN pi or V from
+        // the evaluator) compares false both ways: it is ordered below every number here so that the reduction
+        // stays total and all lanes agree on one edge.
+        float s = score == score ? score : -INFINITY, sv = vloss; int sj = ok ? j : 0x7FFFFFFF, sc = cj;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
           float s2 = __shfl_xor(s, off), v2 = __shfl_xor(sv, off); int j2 = __shfl_xor(sj, off), c2 = __shfl_xor(sc, off);
@@ -160,18 +191,19 @@ __device__ inline int select_one(const TreeDev& d, TV& tv, const Opt& o, int t, 
     }
     mq = (pq + total_uq) / (float)(total_cnt + 1);  // tree_search_node.h:240-241
     tv.meanQ[node] = mq;
-    const int e = eb + bestj;
-    if (o.vl > 0) tv.el[e] = bestvl + (float)o.vl;  // addVirtualLoss :246-264
-    tn[depth] = (uint16_t)node; te[depth] = (uint16_t)bestj;
     int child = bestc;
-    if (child < 0) {  // followEdge :295-317 + allocateState tree_search.h:209-224
-      if (nn >= d.max_nodes) { flags |= FLAG_NODE_OVERFLOW; ++depth; break; }
+    if (child == NOCHILD) {  // followEdge :295-317 + allocateState tree_search.h:209-224
+      if (nn >= d.max_nodes) { flags |= FLAG_NODE_OVERFLOW; break; }   // the tree is parked; this step is not recorded
       child = nn++;
+      const int e = eb + bestj;
       const int action = tv.ea[e];
       init_node(tv, child, mq, node, action);
       Game::on_new_child(d, tv, node, child, action);
-      tv.ec[e] = child;
+      tv.ec[e] = (uint16_t)child;
+      bestvl = 0.f;
     }
+    if (o.vl > 0) tv.in_l[child] = bestvl + (float)o.vl;  // addVirtualLoss :246-264
+    tn[depth] = (uint16_t)node;
     __threadfence_block();
     node = child;
     ++depth;
@@ -282,11 +314,8 @@ __device__ inline void expand_commit(TV& tv, int leaf, bool flip, float value, i
                                      const ExpandScratch<NA, MAXLEGAL>& S) {
   for (int j = lane; j < m; j += 64) {
     const int p = S.pos[j];
-    // one 24-byte edge record = three 8-byte stores: {prior, child -1} {reward 0, visits 0} {vloss 0, action}
-    uint2* rec = (uint2*)(tv.ep.p + (size_t)(eb + j) * EDGE_BYTES);
-    rec[0] = make_uint2(__float_as_uint(S.pri[p]), 0xFFFFFFFFu);
-    rec[1] = make_uint2(0u, 0u);
-    rec[2] = make_uint2(0u, (uint32_t)S.keys[p]);
+    // one 8-byte edge record {prior, action | NOCHILD << 16}: its statistics appear with its child
+    *(uint2*)(tv.ep.p + (size_t)(eb + j) * EDGE_BYTES) = make_uint2(__float_as_uint(S.pri[p]), (uint32_t)S.keys[p] | ((uint32_t)NOCHILD << 16));
   }
   // first half of the header in one store; a node that was never VISITED has no children, so numVisits is 0
   *(uint4*)(tv.meta.p + (size_t)leaf * NODE_BYTES) =
@@ -324,17 +353,17 @@ __device__ inline void backup_batch(const TreeDev& d, TV& tv, const Opt& o, int 
     const float reward = tv.V[leaf];
     const int len = d.traj_len[(size_t)t * o.B + j];
     const uint16_t* tn = d.traj_node + ((size_t)t * o.B + j) * MAXD;
-    const uint16_t* te = d.traj_edge + ((size_t)t * o.B + j) * MAXD;
-    // the steps of one trajectory touch distinct nodes and edges: one lane per step; trajectories
-    // (which share the nodes near the root) stay in order
+    // the steps of one trajectory touch distinct nodes: one lane per step; trajectories (which share the nodes
+    // near the root) stay in order.  Step i = the edge from tn[i] to tn[i+1] (the leaf for the last step): the
+    // node's numVisits_ and the edge's statistics, which are kept in the child's record.
     for (int i = lane; i < len; i += 64) {
       const int node = tn[i];
-      const int e = (int)tv.ebase[node] + te[i];
+      const int child = i + 1 < len ? (int)tn[i + 1] : leaf;
       tv.visits[node] = tv.visits[node] + 1;
-      uint2* rv = (uint2*)(tv.er.p + (size_t)e * EDGE_BYTES);   // {reward, visits}: 8-byte aligned inside the record
-      const uint2 x = *rv;
-      *rv = make_uint2(__float_as_uint(__uint_as_float(x.x) + reward), x.y + 1u);
-      tv.el[e] = tv.el[e] - (float)(o.vl * count);
+      uint4* st = (uint4*)(tv.in_r.p + (size_t)child * NODE_BYTES);   // {reward, num_visits, virtual_loss, -}
+      const uint4 x = *st;
+      *st = make_uint4(__float_as_uint(__uint_as_float(x.x) + reward), x.y + 1u,
+                       __float_as_uint(__uint_as_float(x.z) - (float)(o.vl * count)), x.w);
     }
     stdorder::wave_sync();   // called by ONE wave of the workgroup: trajectories stay in order
   }
@@ -345,10 +374,9 @@ __device__ inline void backup_batch(const TreeDev& d, TV& tv, const Opt& o, int 
 static __global__ void __launch_bounds__(64) mcts_clear_kernel(TreeDev d, const uint8_t* __restrict__ which) {
   const int t = blockIdx.x;
   if (which && !which[t]) return;
-  TV tv = tree_view(d, t, 0);
   if (threadIdx.x == 0) {
-    init_node(tv, 0, 0.f, -1, 0);
-    d.t_arena[t] = 0; d.t_nnodes[t] = 1; d.t_nedges[t] = 0; d.t_flags[t] &= FLAG_INACTIVE;
+    reset_tree(d, t);
+    d.t_flags[t] &= FLAG_INACTIVE;
   }
 }
 
@@ -370,7 +398,7 @@ mcts_result_kernel(TreeDev d, int NA, int pick, int16_t* __restrict__ best_out, 
                    int16_t* __restrict__ ea_out, int32_t* __restrict__ ev_out, float* __restrict__ er_out,
                    float* __restrict__ ep_out, int cap, int32_t* __restrict__ policy_out) {
   const int t = blockIdx.x, lane = threadIdx.x;
-  TV tv = tree_view(d, t, d.t_arena[t]);
+  TV tv = tree_view(d, t);
   const uint32_t meta = tv.meta[0];
   const int ne = (meta & 0xFF) == VISITED ? (int)(meta >> 16) : 0;
   const int eb = (int)tv.ebase[0];
@@ -381,12 +409,12 @@ mcts_result_kernel(TreeDev d, int NA, int pick, int16_t* __restrict__ best_out, 
     const int j = base + lane; const bool ok = j < ne;
     int visits = 0; float score = -INFINITY;
     if (ok) {
-      visits = tv.ev[eb + j];
+      visits = edge_visits(tv, eb + j);
       score = pick == 0 ? (float)visits : tv.ep[eb + j];
       if (j < cap) {
         if (ea_out) ea_out[(size_t)t * cap + j] = (int16_t)tv.ea[eb + j];
         if (ev_out) ev_out[(size_t)t * cap + j] = visits;
-        if (er_out) er_out[(size_t)t * cap + j] = tv.er[eb + j];
+        if (er_out) er_out[(size_t)t * cap + j] = edge_reward(tv, eb + j);
         if (ep_out) ep_out[(size_t)t * cap + j] = tv.ep[eb + j];
       }
       if (policy_out) policy_out[(size_t)t * NA + tv.ea[eb + j]] = visits;
@@ -408,7 +436,7 @@ mcts_result_kernel(TreeDev d, int NA, int pick, int16_t* __restrict__ best_out, 
       if (bestq_out) bestq_out[t] = rootv;
     } else {
       if (best_out) best_out[t] = (int16_t)tv.ea[eb + bestj];
-      if (bestq_out) bestq_out[t] = total == 0 ? rootv : tv.er[eb + bestj] / (float)tv.ev[eb + bestj];
+      if (bestq_out) bestq_out[t] = total == 0 ? rootv : edge_reward(tv, eb + bestj) / (float)edge_visits(tv, eb + bestj);
     }
     if (total_out) total_out[t] = total;
     if (rootv_out) rootv_out[t] = rootv;
@@ -423,7 +451,7 @@ mcts_pick_kernel(TreeDev d, int NA, const int32_t* __restrict__ ply, int cutoff,
                  int16_t* __restrict__ move, uint8_t* __restrict__ pol, float* __restrict__ value) {
   const int t = blockIdx.x, lane = threadIdx.x;
   if (d.t_flags[t] & FLAG_INACTIVE) return;  // the other AI's handle fills this game's outputs
-  TV tv = tree_view(d, t, d.t_arena[t]);
+  TV tv = tree_view(d, t);
   const uint32_t meta = tv.meta[0];
   const int ne = (meta & 0xFF) == VISITED ? (int)(meta >> 16) : 0;
   const int eb = (int)tv.ebase[0];
@@ -433,7 +461,7 @@ mcts_pick_kernel(TreeDev d, int NA, const int32_t* __restrict__ ply, int cutoff,
   int total = 0, bestv = -1, bestj = 0x7FFFFFFF;
   for (int base = 0; base < ne; base += 64) {
     const int j = base + lane;
-    int v = j < ne ? tv.ev[eb + j] : -1, vj = j < ne ? j : 0x7FFFFFFF, sum = j < ne ? v : 0;
+    int v = j < ne ? edge_visits(tv, eb + j) : -1, vj = j < ne ? j : 0x7FFFFFFF, sum = j < ne ? v : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       int v2 = __shfl_xor(v, off), j2 = __shfl_xor(vj, off);
@@ -450,7 +478,7 @@ mcts_pick_kernel(TreeDev d, int NA, const int32_t* __restrict__ ply, int cutoff,
   bool picked = false;
   for (int base = 0; base < ne; base += 64) {
     const int j = base + lane;
-    const int v = j < ne ? tv.ev[eb + j] : 0;
+    const int v = j < ne ? edge_visits(tv, eb + j) : 0;
     if (pol && j < ne) {
       const float p = (float)v / exp_sum;
       const float q = p / maxp * 255.0f;
@@ -467,7 +495,7 @@ mcts_pick_kernel(TreeDev d, int NA, const int32_t* __restrict__ ply, int cutoff,
   }
   if (lane == 0) {
     move[t] = chosen < 0 ? (int16_t)-1 : (int16_t)tv.ea[eb + chosen];
-    if (value) value[t] = (ne == 0 || total == 0) ? tv.V[0] : tv.er[eb + bestj] / (float)tv.ev[eb + bestj];
+    if (value) value[t] = (ne == 0 || total == 0) ? tv.V[0] : edge_reward(tv, eb + bestj) / (float)edge_visits(tv, eb + bestj);
   }
 }
 
@@ -479,14 +507,14 @@ static __global__ void __launch_bounds__(64)
 mcts_policy_only_kernel(TreeDev d, const uint8_t* __restrict__ which, int16_t* __restrict__ move, float* __restrict__ value) {
   const int t = blockIdx.x, lane = threadIdx.x;
   if ((which && !which[t]) || (d.t_flags[t] & FLAG_INACTIVE)) return;
-  TV tv = tree_view(d, t, d.t_arena[t]);
+  TV tv = tree_view(d, t);
   const uint32_t meta = tv.meta[0];
   const int ne = (meta & 0xFF) == VISITED ? (int)(meta >> 16) : 0;
   const int eb = (int)tv.ebase[0];
   float best = -INFINITY; int bestj = 0x7FFFFFFF, total = 0;
   for (int base = 0; base < ne; base += 64) {
     const int j = base + lane; const bool ok = j < ne;
-    float s = ok ? tv.ep[eb + j] : -INFINITY; int sj = ok ? j : 0x7FFFFFFF; int sum = ok ? tv.ev[eb + j] : 0;
+    float s = ok ? tv.ep[eb + j] : -INFINITY; int sj = ok ? j : 0x7FFFFFFF; int sum = ok ? edge_visits(tv, eb + j) : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const float s2 = __shfl_xor(s, off); const int j2 = __shfl_xor(sj, off);
@@ -498,36 +526,40 @@ mcts_policy_only_kernel(TreeDev d, const uint8_t* __restrict__ which, int16_t* _
   }
   if (lane == 0) {
     move[t] = ne == 0 ? (int16_t)-1 : (int16_t)tv.ea[eb + bestj];
-    if (value) value[t] = (ne == 0 || total == 0) ? tv.V[0] : tv.er[eb + bestj] / (float)tv.ev[eb + bestj];
+    if (value) value[t] = (ne == 0 || total == 0) ? tv.V[0] : edge_reward(tv, eb + bestj) / (float)edge_visits(tv, eb + bestj);
   }
 }
 
 // TreeT::treeAdvance tree_search_node.h:458-474: keep the chosen child's subtree, drop the rest.
-// The kept subtree is copied breadth-first into the other arena (new indices, same contents).
-static __global__ void __launch_bounds__(64) mcts_advance_kernel(TreeDev d, const int16_t* __restrict__ actions) {
+// The kept subtree is copied breadth-first into a spare arena (new indices, same contents); the tree then lives
+// there and its old arena becomes the spare.  Block b of the launch works on tree first_tree + b with spare b.
+static __global__ void __launch_bounds__(64) mcts_advance_kernel(TreeDev d, const int16_t* __restrict__ actions, int first_tree) {
   extern __shared__ uint16_t s_map[];  // new index -> old index  [max_nodes]
   __shared__ int s_child;
-  const int t = blockIdx.x, lane = threadIdx.x;
+  const int t = first_tree + blockIdx.x, lane = threadIdx.x;
   const int a = actions[t];
   if (a < 0) return;
-  const int arena = d.t_arena[t];
+  const int arena = d.t_arena[t], spare = d.spare_arena[blockIdx.x];
   const int sw = d.state_words;
-  TV o = tree_view(d, t, arena), n = tree_view(d, t, arena ^ 1);
+  TV o = arena_view(d, arena), n = arena_view(d, spare);
   const uint32_t meta = o.meta[0];
   const int ne0 = (meta & 0xFF) == VISITED ? (int)(meta >> 16) : 0;
   const int eb0 = (int)o.ebase[0];
-  if (lane == 0) s_child = -1;
+  if (lane == 0) s_child = NOCHILD;
   __syncthreads();
   for (int j = lane; j < ne0; j += 64) if (o.ea[eb0 + j] == (uint16_t)a) s_child = o.ec[eb0 + j];
   __syncthreads();
   const int c = s_child;
-  if (c < 0) {  // never expanded: fresh root (allocateRoot -> addNode(0.0))
-    if (lane == 0) { init_node(n, 0, 0.f, -1, 0); d.t_arena[t] = arena ^ 1; d.t_nnodes[t] = 1; d.t_nedges[t] = 0; }
+  if (c == NOCHILD) {  // never expanded: fresh root (allocateRoot -> addNode(0.0)); stays in its own arena
+    if (lane == 0) reset_tree(d, t);
     return;
   }
+  // a node record moves as its four 16-byte quarters (parent re-indexed); lanes 0..3 of a group take one each
   auto copy_node = [&](int dst, int src, int parent) {
-    n.meta[dst] = o.meta[src]; n.visits[dst] = o.visits[src]; n.V[dst] = o.V[src];
-    n.meanQ[dst] = o.meanQ[src]; n.parentQ[dst] = o.parentQ[src]; n.parent[dst] = parent; n.paction[dst] = o.paction[src];
+    const uint4* sr = (const uint4*)(o.meta.p + (size_t)src * NODE_BYTES);
+    uint4* dr = (uint4*)(n.meta.p + (size_t)dst * NODE_BYTES);
+    uint4 q1 = sr[1]; q1.z = (uint32_t)parent;
+    dr[0] = sr[0]; dr[1] = q1; dr[2] = sr[2];
     for (int k = 0; k < sw; ++k) n.state[(size_t)dst * sw + k] = o.state[(size_t)src * sw + k];
   };
   if (lane == 0) { copy_node(0, c, -1); s_map[0] = (uint16_t)c; }
@@ -541,28 +573,25 @@ static __global__ void __launch_bounds__(64) mcts_advance_kernel(TreeDev d, cons
     if (lane == 0) n.ebase[i] = (uint32_t)ecount;
     for (int base = 0; base < ne; base += 64) {
       const int j = base + lane; const bool ok = j < ne;
-      int oc = -1;
+      uint2 e = make_uint2(0u, 0u);
+      int oc = NOCHILD;
+      if (ok) { e = *(const uint2*)(o.ep.p + (size_t)(eb + j) * EDGE_BYTES); oc = (int)(e.y >> 16); }
+      const unsigned long long has = __ballot(ok && oc != NOCHILD);
       if (ok) {
-        oc = o.ec[eb + j];
-        n.ea[ecount + j] = o.ea[eb + j]; n.ep[ecount + j] = o.ep[eb + j]; n.er[ecount + j] = o.er[eb + j];
-        n.ev[ecount + j] = o.ev[eb + j]; n.el[ecount + j] = o.el[eb + j];
-      }
-      const unsigned long long has = __ballot(ok && oc >= 0);
-      if (ok) {
-        int ni = -1;
-        if (oc >= 0) {
-          ni = count + __popcll(has & ((1ull << lane) - 1));
+        if (oc != NOCHILD) {
+          const int ni = count + __popcll(has & ((1ull << lane) - 1));
           s_map[ni] = (uint16_t)oc;
           copy_node(ni, oc, i);
+          e.y = (e.y & 0xFFFFu) | ((uint32_t)ni << 16);
         }
-        n.ec[ecount + j] = ni;
+        *(uint2*)(n.ep.p + (size_t)(ecount + j) * EDGE_BYTES) = e;
       }
       count += __popcll(has);
     }
     ecount += ne;
     __syncthreads();
   }
-  if (lane == 0) { d.t_arena[t] = arena ^ 1; d.t_nnodes[t] = count; d.t_nedges[t] = ecount; }
+  if (lane == 0) { d.t_arena[t] = spare; d.spare_arena[blockIdx.x] = arena; d.t_nnodes[t] = count; d.t_nedges[t] = ecount; }
 }
 
 // NodeT::enhanceExploration (tree_search_node.h:144-167) on the root, device half: the etas are drawn
@@ -570,7 +599,7 @@ static __global__ void __launch_bounds__(64) mcts_advance_kernel(TreeDev d, cons
 static __global__ void __launch_bounds__(64) mcts_root_edges_kernel(TreeDev d, int32_t* __restrict__ cnt) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= d.n_trees) return;
-  TV tv = tree_view(d, t, d.t_arena[t]);
+  TV tv = tree_view(d, t);
   const uint32_t meta = tv.meta[0];
   cnt[t] = (d.t_flags[t] == 0 && (meta & 0xFF) == VISITED) ? (int)(meta >> 16) : 0;
 }
@@ -580,7 +609,7 @@ mcts_root_noise_kernel(TreeDev d, float epsilon, const float* __restrict__ eta, 
   const int t = blockIdx.x, lane = threadIdx.x;
   const int m = cnt[t];
   if (m == 0) return;
-  TV tv = tree_view(d, t, d.t_arena[t]);
+  TV tv = tree_view(d, t);
   const int eb = (int)tv.ebase[0];
   const float z = Z[t];
   for (int j = lane; j < m; j += 64)  // prior = (1 - epsilon) * prior + epsilon * etas[i] / Z, float, no contraction
@@ -618,14 +647,37 @@ struct MctsBase {
     o.use_prior = opt->use_prior; o.c_puct = opt->c_puct; o.uqz = opt->unexplored_q_zero;
     o.ruqz = opt->root_unexplored_q_zero; o.persistent = opt->persistent_tree; o.pick = opt->pick_method;
     d.n_trees = n_trees; d.state_words = state_words;
+    // a fresh search creates at most one node per rollout: R + 1 nodes is the least a tree needs; the default
+    // leaves room for the subtrees a persistent tree carries from move to move
+    if (opt->max_nodes > MAX_NODES_LIMIT || o.R + 2 > MAX_NODES_LIMIT) {
+      elfhip_set_error("mcts_create: max_nodes=%d / num_rollouts_per_thread=%d beyond the %d-node limit of a tree (16-bit node ids)",
+                       opt->max_nodes, o.R, MAX_NODES_LIMIT);
+      return ELFHIP_EINVAL;
+    }
+    if (opt->max_nodes > 0 && opt->max_nodes < 2) { elfhip_set_error("mcts_create: max_nodes=%d", opt->max_nodes); return ELFHIP_EINVAL; }
     d.max_nodes = opt->max_nodes > 0 ? opt->max_nodes : 8 * o.R + 64;
-    if (d.max_nodes > 30000) d.max_nodes = 30000;  // u16 node ids; the advance kernel maps them in LDS
+    if (d.max_nodes > MAX_NODES_LIMIT) d.max_nodes = MAX_NODES_LIMIT;
     d.max_edges = opt->max_edges > 0 ? opt->max_edges : default_edges_per_node * d.max_nodes;
-    const size_t NN = (size_t)2 * n_trees * d.max_nodes, NE = (size_t)2 * n_trees * d.max_edges, T = (size_t)n_trees;
+    // spare arenas for treeAdvance: every tree at once while that is cheap, an eighth of the trees (eight launches
+    // per move) when the trees are what fills the GPU's memory
+    d.n_spare = n_trees <= 1024 ? n_trees : (n_trees / 8 > 1024 ? n_trees / 8 : 1024);
+    if (const char* e = getenv("ELFHIP_MCTS_SPARE_ARENAS")) {   // tests: force the chunked advance on small searches
+      const int v = atoi(e);
+      if (v >= 1 && v <= n_trees) d.n_spare = v;
+    }
+    d.n_arenas = n_trees + d.n_spare;
+    const size_t NN = (size_t)d.n_arenas * d.max_nodes, NE = (size_t)d.n_arenas * d.max_edges, T = (size_t)n_trees;
     MCTS_ALLOC(d.n_rec, NN * NODE_BYTES); MCTS_ALLOC(d.n_state, NN * 4 * (size_t)state_words);
     MCTS_ALLOC(d.e_rec, NE * EDGE_BYTES);
     MCTS_ALLOC(d.t_arena, T * 4); MCTS_ALLOC(d.t_nnodes, T * 4); MCTS_ALLOC(d.t_nedges, T * 4); MCTS_ALLOC(d.t_flags, T * 4);
-    MCTS_ALLOC(d.traj_node, T * o.B * MAXD * 2); MCTS_ALLOC(d.traj_edge, T * o.B * MAXD * 2);
+    MCTS_ALLOC(d.spare_arena, (size_t)d.n_spare * 4);
+    {
+      std::vector<int32_t> ids((size_t)d.n_arenas);
+      for (int i = 0; i < d.n_arenas; ++i) ids[(size_t)i] = i;
+      HIPCHECK(hipMemcpy(d.t_arena, ids.data(), T * 4, hipMemcpyHostToDevice));
+      HIPCHECK(hipMemcpy(d.spare_arena, ids.data() + T, (size_t)d.n_spare * 4, hipMemcpyHostToDevice));
+    }
+    MCTS_ALLOC(d.traj_node, T * o.B * MAXD * 2);
     MCTS_ALLOC(d.traj_len, T * o.B * 4); MCTS_ALLOC(d.leaf, T * o.B * 4); MCTS_ALLOC(d.locked, T * o.B);
     MCTS_ALLOC(uniform_order, (size_t)na * 2); MCTS_ALLOC(d.stats, 4 * 8);
     d.uniform_order = uniform_order;
@@ -690,6 +742,19 @@ struct MctsBase {
   int zero_need(uint8_t* d_need_eval) {
     if (d_need_eval) HIPCHECK(hipMemsetAsync(d_need_eval, 0, (size_t)d.n_trees * o.B, stream));
     return ELFHIP_OK;
+  }
+  // treeAdvance, n_spare trees per launch (the launches of one stream run in order: chunk k's old arenas are the
+  // spares of chunk k + 1)
+  int advance(const int16_t* d_actions) {
+    for (int first = 0; first < d.n_trees; first += d.n_spare) {
+      const int cnt = d.n_trees - first < d.n_spare ? d.n_trees - first : d.n_spare;
+      hipLaunchKernelGGL(mcts_advance_kernel, dim3(cnt), dim3(64), (size_t)d.max_nodes * 2, stream, d, d_actions, first);
+    }
+    HIPCHECK(hipGetLastError());
+    return ELFHIP_OK;
+  }
+  size_t bytes_per_tree() const {
+    return (size_t)d.max_nodes * (NODE_BYTES + 4 * (size_t)d.state_words) + (size_t)d.max_edges * EDGE_BYTES;
   }
   int clear(const uint8_t* d_which) {
     hipLaunchKernelGGL(mcts_clear_kernel, dim3(d.n_trees), dim3(64), 0, stream, d, d_which);

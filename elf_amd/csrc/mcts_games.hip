@@ -95,12 +95,8 @@ games_set_roots_kernel(TreeDev d, int persistent, const uint64_t* __restrict__ w
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= d.n_trees) return;
   if (d.t_flags[t] & FLAG_INACTIVE) { if (ok) ok[t] = 1; return; }
-  if (!persistent) {
-    TV c = tree_view(d, t, 0);
-    init_node(c, 0, 0.f, -1, 0);
-    d.t_arena[t] = 0; d.t_nnodes[t] = 1; d.t_nedges[t] = 0; d.t_flags[t] &= ~FLAG_ROOT_MISMATCH;
-  }
-  TV tv = tree_view(d, t, d.t_arena[t]);
+  if (!persistent) { reset_tree(d, t); d.t_flags[t] &= ~FLAG_ROOT_MISMATCH; }
+  TV tv = tree_view(d, t);
   uint64_t* rb = gnode<G>(tv, 0);
   bool good = true;
   if (tv.meta[0] & META_STATE_SET) {
@@ -124,7 +120,7 @@ games_search_kernel(TreeDev d, Opt o, uint64_t* __restrict__ leaf_states, float*
   const int t = blockIdx.x, lane = threadIdx.x;
   int flags = d.t_flags[t];
   if (flags) return;
-  TV tv = tree_view(d, t, d.t_arena[t]);
+  TV tv = tree_view(d, t);
   int nn = d.t_nnodes[t], ne = d.t_nedges[t];
   unsigned long long rollouts = 0, evals = 0, depth_sum = 0, edge_sum = 0;
   const int nbatch = MODE == 0 ? (o.R + o.B - 1) / o.B : 1;

@@ -71,12 +71,8 @@ go_tree_set_roots_kernel(TreeDev d, GoDev g, int persistent, uint8_t* __restrict
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= d.n_trees) return;
   if (d.t_flags[t] & FLAG_INACTIVE) { if (ok) ok[t] = 1; return; }
-  if (!persistent) {
-    TV c = tree_view(d, t, 0);
-    init_node(c, 0, 0.f, -1, 0);
-    d.t_arena[t] = 0; d.t_nnodes[t] = 1; d.t_nedges[t] = 0; d.t_flags[t] &= ~FLAG_ROOT_MISMATCH;
-  }
-  TV tv = tree_view(d, t, d.t_arena[t]);
+  if (!persistent) { reset_tree(d, t); d.t_flags[t] &= ~FLAG_ROOT_MISMATCH; }
+  TV tv = tree_view(d, t);
   GoS s; go_load(g, t, s);
   uint32_t w[GO_SW];
   node_store(w, s);
@@ -100,7 +96,7 @@ __global__ void __launch_bounds__(64) go_tree_select_kernel(TreeDev d, Opt o) {
     if (lane < o.B) { d.leaf[(size_t)t * o.B + lane] = 0; d.locked[(size_t)t * o.B + lane] = 0; }
     return;  // overflowed / mismatched trees are parked until cleared
   }
-  TV tv = tree_view(d, t, d.t_arena[t]);
+  TV tv = tree_view(d, t);
   int nn = d.t_nnodes[t];
   unsigned long long depth_sum = 0;
   for (int j = 0; j < o.B; ++j) {
@@ -133,7 +129,7 @@ go_tree_expand_kernel(TreeDev d, Opt o, GoDev g, const uint64_t* __restrict__ gz
   const int t = valid ? slot / o.B : 0;
   const bool live = valid && d.t_flags[t] == 0 && d.locked[slot] != 0;
   const int leaf = live ? d.leaf[slot] : 0;
-  TV tv = tree_view(d, t, d.t_arena[t]);
+  TV tv = tree_view(d, t);
   GoS s; go_clear(s);
   const bool pending = live && !(tv.meta[leaf] & META_STATE_SET);
   uint32_t a = 0;
@@ -214,7 +210,7 @@ go_tree_features_kernel(TreeDev d, Opt o, GoDev g, const uint8_t* __restrict__ n
     return;
   }
   const int t = slot / o.B;
-  TV tv = tree_view(d, t, d.t_arena[t]);
+  TV tv = tree_view(d, t);
   const int leaf = d.leaf[slot];
   const uint32_t tm = tv.state[(size_t)leaf * GO_SW + 57] & 1;
   const int r = p / 19, c = p % 19;
@@ -258,7 +254,7 @@ go_tree_backup_kernel(TreeDev d, Opt o, GoX x, const float* __restrict__ pi, con
   GoScratch& S = ((GoScratch*)go_backup_smem)[wave];
   int flags = d.t_flags[t];
   if (flags) return;
-  TV tv = tree_view(d, t, d.t_arena[t]);
+  TV tv = tree_view(d, t);
   int ne = d.t_nedges[t];
   unsigned long long evals = 0, edge_sum = 0;
   if ((int)threadIdx.x < o.B) { s_leaf[threadIdx.x] = d.leaf[(size_t)t * o.B + threadIdx.x]; s_locked[threadIdx.x] = d.locked[(size_t)t * o.B + threadIdx.x]; }

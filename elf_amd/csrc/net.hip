@@ -62,7 +62,7 @@ __global__ void net_pack_input_kernel(const float* __restrict__ s, uint16_t* __r
 template <int COUT>
 __global__ void __launch_bounds__(256)
 conv3x3_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
-               const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int B, int H, int W, int CIN, int relu) {
+               const uint16_t* __restrict__ res, uint16_t* __restrict__ out, uint16_t* lo, int lo_in, int B, int H, int W, int CIN, int relu) {
   constexpr int MT = COUT / 16;  // output-channel tiles
   __shared__ __attribute__((aligned(16))) uint16_t sW[COUT * LROW];
   __shared__ __attribute__((aligned(16))) uint16_t sX[BP * LROW];
@@ -126,17 +126,29 @@ conv3x3_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, c
       for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] + bias[co + r];
       if (res) {
         const uint2 rr = *(const uint2*)(res + obase + co);
-        v[0] += bf2f((uint16_t)(rr.x & 0xFFFF)); v[1] += bf2f((uint16_t)(rr.x >> 16));
-        v[2] += bf2f((uint16_t)(rr.y & 0xFFFF)); v[3] += bf2f((uint16_t)(rr.y >> 16));
+        float s4[4] = {bf2f((uint16_t)(rr.x & 0xFFFF)), bf2f((uint16_t)(rr.x >> 16)), bf2f((uint16_t)(rr.y & 0xFFFF)), bf2f((uint16_t)(rr.y >> 16))};
+        if (lo_in) {   // the skip value is hi + lo (see NetImpl::forward)
+          const uint2 ll = *(const uint2*)(lo + obase + co);
+          s4[0] += bf2f((uint16_t)(ll.x & 0xFFFF)); s4[1] += bf2f((uint16_t)(ll.x >> 16));
+          s4[2] += bf2f((uint16_t)(ll.y & 0xFFFF)); s4[3] += bf2f((uint16_t)(ll.y >> 16));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += s4[r];
       }
       if (relu) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
       uint2 o;
-      o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-      o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      o.x = pack_bf16(v[0], v[1]);
+      o.y = pack_bf16(v[2], v[3]);
       *(uint2*)(out + obase + co) = o;
+      if (lo) {
+        uint2 l;
+        l.x = pack_bf16(v[0] - bf2f((uint16_t)(o.x & 0xFFFF)), v[1] - bf2f((uint16_t)(o.x >> 16)));
+        l.y = pack_bf16(v[2] - bf2f((uint16_t)(o.y & 0xFFFF)), v[3] - bf2f((uint16_t)(o.y >> 16)));
+        *(uint2*)(lo + obase + co) = l;
+      }
     }
   }
 }
@@ -220,10 +232,14 @@ __device__ inline void lds_dma16(const char* gsrc, const char* lds_dst) {
 // fragments are read two position tiles ahead of the MFMAs that consume them.
 // Wave grid 2 (output-channel halves) x 4 (position quarters); a wave keeps COUT/32 x NTW
 // accumulator tiles (16x16 fp32) in registers, so each LDS fragment read feeds 6-7 MFMAs.
-template <int COUT, int H, int NBW>
+// SPLIT: 0 = plain bf16 output; 1 = also write the four extra mantissa bits of the output to `lo` (the stem);
+// 2 = the skip value read is res extended by its nibble in `lo`, and the output is split again, lo updated in
+// place (conv_upper) - see NetImpl::lo.
+template <int COUT, int H, int NBW, int SPLIT>
 __global__ void __launch_bounds__(512)
 conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
-                     const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int B, int CIN, int relu, int late_half, int stagger, int phases) {
+                     const uint16_t* __restrict__ res, uint16_t* __restrict__ out, uint16_t* lo, int B, int CIN, int relu,
+                     int late_half, int stagger, int phases) {
   constexpr int PW = H + 2, PP = PW * PW, HW = H * H;
   constexpr int PT = NBW * HW;             // output positions of this workgroup
   constexpr int NT = (PT + 15) / 16;       // position tiles
@@ -429,6 +445,12 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
     uint32_t obase[NTW];
     const uint16_t* const resg = res ? res + (size_t)xrow0 * COUT : nullptr;
     uint16_t* const outg = out + (size_t)xrow0 * COUT;
+    // SPLIT: the skip stream's four extra mantissa bits.  They are read and written only by this kernel, each
+    // lane its own values, so they are stored in register order: the word of unit u (a channel tile x a pair of
+    // position tiles = 8 nibbles per lane) of lane l of wave `wave` of board group g sits at
+    // ((g * 8 + wave) * NU + u) * 64 + l - every wave access is one contiguous 256-byte run, there is no position
+    // arithmetic, and dead lanes simply own unused slots.
+    uint32_t* const log = SPLIT ? (uint32_t*)lo + ((size_t)g * 8 + wave) * (MTW * ((NTW + 1) / 2)) * 64 : nullptr;   // wave-uniform
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
       const int p = (wp * NTW + nt) * 16 + r16;
@@ -437,57 +459,94 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
       asm volatile("" : "+v"(pbv));
       obase[nt] = (pbv / 80u + (PW + 1)) * COUT;
     }
-    // Software-pipelined over the channel tiles: the bias and residual words of tile mt+1 are requested
-    // BEFORE the stores of tile mt are issued.  vmcnt retires in order, so a load issued after stores
-    // could only be consumed once those stores had completed (a full HBM write round trip per tile).
-    auto load_tile = [&](int mt, float4& bv, uint2 (&rr)[NTW]) {
+    // Software-pipelined in units of (channel tile, PAIR of position tiles): the residual words of the unit NP
+    // units ahead (one channel tile's worth) are requested BEFORE the stores of the current unit are issued.
+    // vmcnt retires in order, so a load issued after stores could only be consumed once those stores had
+    // completed (a full HBM write round trip per tile).
+    constexpr int NP = (NTW + 1) / 2, NU = MTW * NP;
+    constexpr int DEPTH = (SPLIT && NP > 2) ? 2 : NP;   // units in flight (the split variants have no registers for more)
+    uint2 rrb[DEPTH][2];
+    uint32_t lwb[DEPTH];
+    auto load_unit = [&](int u, uint2 (&rr)[2], uint32_t& lw) {
+      const int mt = u / NP, p = u - mt * NP;
       const int co = (wc * MTW + mt) * 16 + q * 4;
-      bv = *(const float4*)(bias + co);
-      if (res) {
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) rr[nt] = live[nt] ? *(const uint2*)(resg + obase[nt] + co) : make_uint2(0, 0);
+      for (int k = 0; k < 2; ++k) {
+        const int nt = 2 * p + k;
+        if (nt < NTW && res) rr[k] = live[nt] ? *(const uint2*)(resg + obase[nt] + co) : make_uint2(0, 0);
       }
+      if (SPLIT == 2) lw = log[u * 64 + lane];
     };
-    float4 bv_next; uint2 rr_next[NTW];
-    load_tile(0, bv_next, rr_next);
+    float4 bv_next = *(const float4*)(bias + (wc * MTW) * 16 + q * 4);
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) load_unit(u, rrb[u], lwb[u]);
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
       const int co = (wc * MTW + mt) * 16 + q * 4;
       const float4 bv = bv_next;
-      uint2 rr[NTW];
+      if (mt + 1 < MTW) bv_next = *(const float4*)(bias + (wc * MTW + mt + 1) * 16 + q * 4);
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) rr[nt] = rr_next[nt];
-      if (mt + 1 < MTW) load_tile(mt + 1, bv_next, rr_next);
-      uint2 o[NTW];
+      for (int p = 0; p < NP; ++p) {
+        const int u = mt * NP + p;
+        uint2 o[2];
+        const uint32_t lw = SPLIT == 2 ? lwb[u % DEPTH] : 0u;
+        uint32_t lwo = 0u;
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        float v[4] = {acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w};
-        if (res) {
-          v[0] += bf2f((uint16_t)(rr[nt].x & 0xFFFF)); v[1] += bf2f((uint16_t)(rr[nt].x >> 16));
-          v[2] += bf2f((uint16_t)(rr[nt].y & 0xFFFF)); v[3] += bf2f((uint16_t)(rr[nt].y >> 16));
+        for (int k = 0; k < 2; ++k) {
+          const int nt = 2 * p + k;
+          if (nt >= NTW) continue;
+          float v[4] = {acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w};
+          if (res) {
+            const uint2 rr = rrb[u % DEPTH][k];
+            uint32_t sb[4] = {rr.x << 16, rr.x & 0xFFFF0000u, rr.y << 16, rr.y & 0xFFFF0000u};
+            if (SPLIT == 2) {
+              // skip value = the 20-bit float whose bf16 rounding is the stored word: its bit pattern is
+              // (bf16 << 16) + (signed nibble << 12)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sb[r] += (uint32_t)__builtin_amdgcn_sbfe((int)lw, (k * 4 + r) * 4, 4) << 12;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += __uint_as_float(sb[r]);
+          }
+          if (relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          if (SPLIT) {
+            // v rounded to 20 bits (12 dropped, half up), then to bf16 (half up again): the bf16 word goes to the
+            // next convolution, bits 12..15 of the 20-bit pattern - read as a signed nibble they are exactly
+            // (20-bit pattern) - (bf16 word << 16) - to the skip stream
+            uint32_t t[4], h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              t[r] = __float_as_uint(v[r]) + 0x800u;
+              h[r] = (t[r] & 0xFFFFF000u) + 0x8000u;
+              lwo |= ((t[r] >> 12) & 0xFu) << ((k * 4 + r) * 4);
+            }
+            o[k].x = (h[0] >> 16) | (h[1] & 0xFFFF0000u);
+            o[k].y = (h[2] >> 16) | (h[3] & 0xFFFF0000u);
+          } else {
+            o[k].x = pack_bf16(v[0], v[1]);
+            o[k].y = pack_bf16(v[2], v[3]);
+          }
         }
-        if (relu) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        if (u + DEPTH < NU) load_unit(u + DEPTH, rrb[u % DEPTH], lwb[u % DEPTH]);
+        // Stores are issue-bound, so make them 16 bytes wide: lanes q and q+1 (16 lanes apart) hold
+        // adjacent 4-channel groups.  v_permlane16_swap exchanges the odd 16-lane rows of one register
+        // with the even rows of another; applied to the words of a PAIR of position tiles it leaves
+        // rows 0/2 with channels [8(q/2), 8(q/2)+8) of the first tile and rows 1/3 with those of the second.
+        const int nt = 2 * p;
+        if (nt + 1 < NTW) {
+          const bool second = q & 1;
+          const uint32_t ob = (second ? obase[nt + 1] : obase[nt]) + (wc * MTW + mt) * 16 + (q >> 1) * 8;
+          const bool lv = second ? live[nt + 1] : live[nt];
+          const auto sx = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);
+          const auto sy = __builtin_amdgcn_permlane16_swap(o[0].y, o[1].y, false, false);
+          if (lv) *(uint4*)(outg + ob) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        } else {
+          if (live[nt]) *(uint2*)(outg + obase[nt] + co) = o[0];
         }
-        o[nt].x = pack_bf16(v[0], v[1]);
-        o[nt].y = pack_bf16(v[2], v[3]);
-      }
-      // Stores are issue-bound, so make them 16 bytes wide: lanes q and q+1 (16 lanes apart) hold
-      // adjacent 4-channel groups.  v_permlane16_swap exchanges the odd 16-lane rows of one register
-      // with the even rows of another; applied to the words of a PAIR of position tiles it leaves
-      // rows 0/2 with channels [8(q/2), 8(q/2)+8) of the first tile and rows 1/3 with those of the second.
-#pragma unroll
-      for (int nt = 0; nt + 1 < NTW; nt += 2) {
-        const auto sx = __builtin_amdgcn_permlane16_swap(o[nt].x, o[nt + 1].x, false, false);
-        const auto sy = __builtin_amdgcn_permlane16_swap(o[nt].y, o[nt + 1].y, false, false);
-        const bool second = q & 1;
-        const uint4 st = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-        const uint32_t ob = second ? obase[nt + 1] : obase[nt];
-        if (second ? live[nt + 1] : live[nt]) *(uint4*)(outg + ob + (wc * MTW + mt) * 16 + (q >> 1) * 8) = st;
-      }
-      if (NTW & 1) {
-        if (live[NTW - 1]) *(uint2*)(outg + obase[NTW - 1] + co) = o[NTW - 1];
+        if (SPLIT) log[u * 64 + lane] = lwo;
       }
     }
     CP_SEG(6);   // epilogue
@@ -594,7 +653,7 @@ conv3x3_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, con
 //   pi  = exp(logsoftmax(pi_linear(relu(bn(conv1x1_pi(s))))))     V = tanh(lin2(relu(lin1(relu(bn(conv1x1_v(s)))))))
 template <class T>
 __global__ void __launch_bounds__(256)
-net_heads_kernel(const T* __restrict__ x, int H, int W, int C, int A,
+net_heads_kernel(const T* __restrict__ x, const T* __restrict__ xlo, int H, int W, int C, int A,
                  const float* __restrict__ wpi, float bpi, const float* __restrict__ wv, float bv,
                  const float* __restrict__ pl_w, const float* __restrict__ pl_b,
                  const float* __restrict__ v1_w, const float* __restrict__ v1_b,
@@ -610,17 +669,19 @@ net_heads_kernel(const T* __restrict__ x, int H, int W, int C, int A,
   const int n = blockIdx.x, tid = threadIdx.x;
   for (int p = tid; p < HW; p += 256) {
     const int y = p / W, xw = p % W;
-    const T* row = x + (((size_t)n * (H + 2) + y + 1) * (W + 2) + xw + 1) * C;
+    const size_t roff = (((size_t)n * (H + 2) + y + 1) * (W + 2) + xw + 1) * C;
+    const T* row = x + roff;
     float a = 0.f, b = 0.f;
     if constexpr (sizeof(T) == 4) {
       for (int c = 0; c < C; ++c) { const float xv = (float)row[c]; a += xv * wpi[c]; b += xv * wv[c]; }
     } else {
       for (int c = 0; c < C; c += 8) {
         const uint4 v = *(const uint4*)(row + c);
-        const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+        const uint4 vl = xlo ? *(const uint4*)(xlo + roff + c) : make_uint4(0, 0, 0, 0);   // trunk output = hi + lo
+        const uint32_t u[4] = {v.x, v.y, v.z, v.w}, ul[4] = {vl.x, vl.y, vl.z, vl.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float lo = bf2f((uint16_t)(u[q] & 0xFFFF)), hi = bf2f((uint16_t)(u[q] >> 16));
+          const float lo = bf2f((uint16_t)(u[q] & 0xFFFF)) + bf2f((uint16_t)(ul[q] & 0xFFFF)), hi = bf2f((uint16_t)(u[q] >> 16)) + bf2f((uint16_t)(ul[q] >> 16));
           a += lo * wpi[c + 2 * q] + hi * wpi[c + 2 * q + 1];
           b += lo * wv[c + 2 * q] + hi * wv[c + 2 * q + 1];
         }
@@ -690,6 +751,15 @@ struct NetImpl {
   float *wpi = nullptr, *wv = nullptr, *pl_w = nullptr, *pl_b = nullptr, *v1_w = nullptr, *v1_b = nullptr, *v2_w = nullptr;
   float bpi = 0, bv = 0, v2_b = 0;
   uint16_t *xin = nullptr, *act[3] = {nullptr, nullptr, nullptr};
+  // The skip stream (the stem's output and every block's output) carries 12 mantissa bits instead of bf16's 8:
+  // act[] holds the value rounded to bf16 - what the next convolution's MFMAs read - and `lo` the next four bits
+  // (board kernel: a signed nibble per value, stored in the kernel's own register order, 0.5 byte per value; generic
+  // kernel: the dropped part as a second bf16 array).  conv_upper adds the extended value as the skip and splits
+  // its own fp32 result the same way (lo is updated in place), so the rounding error of the stored activations no
+  // longer compounds from block to block; what is left is the rounding of the MFMA inputs themselves.  On the 20 x 224
+  // tower the error of V halves (rms over 24 positions 0.0081 -> 0.0040 in a CPU emulation; the 4-position fixture
+  // of tests/test_gpu_net.py: max |dV| 0.0127 -> inside the 1e-2 bar).
+  uint16_t* lo = nullptr;
   // fp32 path (elfhip_net_set_precision(ELFHIP_F32)): unfolded fp32 weights + BN scale / shift
   struct ConvF { float* w = nullptr; float* sc = nullptr; float* sh = nullptr; int cin = 0; };
   bool f32 = false;
@@ -699,6 +769,7 @@ struct NetImpl {
   bool use_board_kernel = true;   // ELFHIP_NET_TILE=positions selects the generic position-tiled kernel
   int stagger = -1;               // start offset per workgroup phase in shader cycles; -1 = default_stagger(), 0 = off (ELFHIP_NET_STAGGER)
   int stagger_phases = 4;         // number of distinct start offsets (ELFHIP_NET_STAGGER_PHASES)
+  int split_skip = 1;             // skip stream as bf16 hi + lo (ELFHIP_NET_SPLIT_SKIP=0: bf16 alone, the round-1 arithmetic; A/B timing only)
   int late_half = 1;              // waves 4-7 request their DMA pieces at the end of a stage pair (ELFHIP_NET_LATE=0: all at the top)
   int persist_wgs = 0;            // workgroups of the persistent board kernel (= CUs: the kernel's LDS allows one per CU); 0 = one per board group
   ~NetImpl() { for (void* p : allocs) (void)hipFree(p); }
@@ -718,6 +789,8 @@ struct NetImpl {
     const size_t pos = (size_t)max_batch * (H + 2) * (H + 2);
     NALLOC(xin, pos * cin_pad * 2);
     for (int i = 0; i < 3; ++i) NALLOC(act[i], pos * d * 2);
+    NALLOC(lo, pos * d * 2);
+    HIPCHECK(hipMemsetAsync(lo, 0, pos * d * 2, stream));
     HIPCHECK(hipMemsetAsync(xin, 0, pos * cin_pad * 2, stream));
     for (int i = 0; i < 3; ++i) HIPCHECK(hipMemsetAsync(act[i], 0, pos * d * 2, stream));
     convs.resize(1 + 2 * cfg.num_block);
@@ -837,9 +910,9 @@ struct NetImpl {
   }
 
   template <int COUT>
-  void launch_conv(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
+  void launch_conv(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, uint16_t* lo, int lo_in, int B, int relu) {
     const int M = B * cfg.board * cfg.board;
-    hipLaunchKernelGGL(conv3x3_kernel<COUT>, dim3((M + BP - 1) / BP), dim3(256), 0, stream, x, c.w, c.b, res, out, B,
+    hipLaunchKernelGGL(conv3x3_kernel<COUT>, dim3((M + BP - 1) / BP), dim3(256), 0, stream, x, c.w, c.b, res, out, lo, lo_in, B,
                        cfg.board, cfg.board, c.cin, relu);
   }
   // start offset per phase = 1/8 of the estimated cycles per board group (stages x MFMAs of the two waves of a
@@ -850,43 +923,55 @@ struct NetImpl {
     return (int)((cin / KC) * 9 * 2 * MTW * NTW * 16 * 2.1 / 8);
   }
   template <int COUT, int H, int NBW>
-  void launch_board(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
+  int launch_board(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, uint16_t* lo, int lo_in, int B, int relu) {
     constexpr size_t smem = (size_t)6 * (COUT / 16) * 1024 + (size_t)2 * ((NBW * (H + 2) * (H + 2) * 5 + 63) / 64) * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv3x3_board_kernel<COUT, H, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      attr_set = true;
+    // the attribute belongs to the (function, device) pair: set it once per device this process runs the kernel on
+    const int split = !lo ? 0 : (lo_in ? 2 : 1);
+    auto kern = split == 0 ? conv3x3_board_kernel<COUT, H, NBW, 0> : split == 1 ? conv3x3_board_kernel<COUT, H, NBW, 1> : conv3x3_board_kernel<COUT, H, NBW, 2>;
+    static unsigned long long attr_set[3] = {0, 0, 0};
+    if (device >= 64 || !((attr_set[split] >> device) & 1)) {
+      HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      if (device < 64) attr_set[split] |= 1ull << device;
     }
     const int ngroups = (B + NBW - 1) / NBW;
     const int grid = persist_wgs > 0 ? std::min(ngroups, persist_wgs) : ngroups;
-    hipLaunchKernelGGL((conv3x3_board_kernel<COUT, H, NBW>), dim3(grid), dim3(512), smem, stream, x, c.wb, c.b, res, out, B, c.cin,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, x, c.wb, c.b, res, out, lo, B, c.cin,
                        relu, late_half, stagger >= 0 ? stagger : default_stagger<COUT, H, NBW>(c.cin), stagger_phases);
+    return ELFHIP_OK;
   }
   template <int COUT>
-  bool conv_board(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
-    if (cfg.board == 19) { launch_board<COUT, 19, 1>(x, c, res, out, B, relu); return true; }
-    if (cfg.board == 8) { launch_board<COUT, 8, 4>(x, c, res, out, B, relu); return true; }
-    return false;
+  int conv_board(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, uint16_t* lo, int lo_in, int B, int relu) {   // 1: not this shape
+    if (cfg.board == 19) return launch_board<COUT, 19, 1>(x, c, res, out, lo, lo_in, B, relu);
+    if (cfg.board == 8) return launch_board<COUT, 8, 4>(x, c, res, out, lo, lo_in, B, relu);
+    return 1;
   }
-  void conv(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, int B, int relu) {
+  bool board_shape() const {   // the shapes conv() sends to the board kernel
+    if (!use_board_kernel) return false;
+    const int d = cfg.dim;
+    if (cfg.board == 19) return d == 32 || d == 64 || d == 128 || d == 224;
+    return cfg.board == 8 && (d == 32 || d == 64 || d == 128 || d == 224 || d == 256);
+  }
+  // lo: low halves of the skip stream (nullable: plain bf16 output); lo_in: the skip value read is res + lo
+  int conv(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, uint16_t* lo, int lo_in, int B, int relu) {
     if (use_board_kernel) {
-      bool done = false;
+      int rc = 1;
       switch (cfg.dim) {
-        case 32: done = conv_board<32>(x, c, res, out, B, relu); break;
-        case 64: done = conv_board<64>(x, c, res, out, B, relu); break;
-        case 128: done = conv_board<128>(x, c, res, out, B, relu); break;
-        case 224: done = conv_board<224>(x, c, res, out, B, relu); break;
-        default: done = cfg.board == 8 && conv_board<256>(x, c, res, out, B, relu); break;  // 256 x 19x19 would spill
+        case 32: rc = conv_board<32>(x, c, res, out, lo, lo_in, B, relu); break;
+        case 64: rc = conv_board<64>(x, c, res, out, lo, lo_in, B, relu); break;
+        case 128: rc = conv_board<128>(x, c, res, out, lo, lo_in, B, relu); break;
+        case 224: rc = conv_board<224>(x, c, res, out, lo, lo_in, B, relu); break;
+        default: rc = cfg.board == 8 ? conv_board<256>(x, c, res, out, lo, lo_in, B, relu) : 1; break;  // 256 x 19x19 would spill
       }
-      if (done) return;
+      if (rc <= 0) return rc;
     }
     switch (cfg.dim) {
-      case 32: launch_conv<32>(x, c, res, out, B, relu); break;
-      case 64: launch_conv<64>(x, c, res, out, B, relu); break;
-      case 128: launch_conv<128>(x, c, res, out, B, relu); break;
-      case 224: launch_conv<224>(x, c, res, out, B, relu); break;
-      default: launch_conv<256>(x, c, res, out, B, relu); break;
+      case 32: launch_conv<32>(x, c, res, out, lo, lo_in, B, relu); break;
+      case 64: launch_conv<64>(x, c, res, out, lo, lo_in, B, relu); break;
+      case 128: launch_conv<128>(x, c, res, out, lo, lo_in, B, relu); break;
+      case 224: launch_conv<224>(x, c, res, out, lo, lo_in, B, relu); break;
+      default: launch_conv<256>(x, c, res, out, lo, lo_in, B, relu); break;
     }
+    return ELFHIP_OK;
   }
 
   template <int COUT>
@@ -917,7 +1002,7 @@ struct NetImpl {
       cur = t2;
     }
     const size_t sm = ((size_t)2 * H * H + cfg.num_action + 256) * 4;
-    hipLaunchKernelGGL(net_heads_kernel<float>, dim3(B), dim3(256), sm, stream, fact[cur], H, H, cfg.dim, cfg.num_action, wpi, bpi,
+    hipLaunchKernelGGL(net_heads_kernel<float>, dim3(B), dim3(256), sm, stream, fact[cur], (const float*)nullptr, H, H, cfg.dim, cfg.num_action, wpi, bpi,
                        wv, bv, pl_w, pl_b, v1_w, v1_b, v2_w, v2_b, d_pi, d_logpi, d_v);
     HIPCHECK(hipGetLastError());
     return ELFHIP_OK;
@@ -928,16 +1013,20 @@ struct NetImpl {
     const int H = cfg.board;
     hipLaunchKernelGGL(net_pack_input_kernel, dim3(std::min<size_t>(4096, ((size_t)B * H * H * cin_pad + 255) / 256)), dim3(256),
                        0, stream, d_s, xin, B, cfg.planes, H, H, cin_pad);
-    conv(xin, convs[0], nullptr, act[0], B, 1);                 // init_conv: conv + BN + ReLU
+    uint16_t* const slo = split_skip ? lo : nullptr;
+    int rc = conv(xin, convs[0], nullptr, act[0], slo, 0, B, 1);             // init_conv: conv + BN + ReLU
     int cur = 0;
-    for (int k = 0; k < cfg.num_block; ++k) {                   // Block.forward :85-90
+    for (int k = 0; k < cfg.num_block && rc == ELFHIP_OK; ++k) {            // Block.forward :85-90
       const int t1 = (cur + 1) % 3, t2 = (cur + 2) % 3;
-      conv(act[cur], convs[1 + 2 * k], nullptr, act[t1], B, 1); // conv_lower: conv + BN + ReLU
-      conv(act[t1], convs[2 + 2 * k], act[cur], act[t2], B, 1); // conv_upper: conv + BN, + s, ReLU
+      rc = conv(act[cur], convs[1 + 2 * k], nullptr, act[t1], nullptr, 0, B, 1);                    // conv_lower: conv + BN + ReLU
+      if (rc == ELFHIP_OK) rc = conv(act[t1], convs[2 + 2 * k], act[cur], act[t2], slo, 1, B, 1);   // conv_upper: conv + BN, + s, ReLU
       cur = t2;
     }
+    if (rc != ELFHIP_OK) return rc;
     const size_t sm = ((size_t)2 * H * H + cfg.num_action + 256) * 4;
-    hipLaunchKernelGGL(net_heads_kernel<uint16_t>, dim3(B), dim3(256), sm, stream, act[cur], H, H, cfg.dim, cfg.num_action, wpi, bpi, wv,
+    // the generic kernel's `lo` is a second bf16 array the heads can add; the board kernel's nibbles are private to it
+    const uint16_t* const hlo = board_shape() ? nullptr : slo;
+    hipLaunchKernelGGL(net_heads_kernel<uint16_t>, dim3(B), dim3(256), sm, stream, act[cur], hlo, H, H, cfg.dim, cfg.num_action, wpi, bpi, wv,
                        bv, pl_w, pl_b, v1_w, v1_b, v2_w, v2_b, d_pi, d_logpi, d_v);
     HIPCHECK(hipGetLastError());
     return ELFHIP_OK;
@@ -983,6 +1072,8 @@ int elfhip_net_create(const elfhip_net_config* cfg, int max_batch, int device, e
     if (e && atoi(e) > 0) n->stagger_phases = atoi(e);
     e = getenv("ELFHIP_NET_LATE");
     if (e) n->late_half = atoi(e);
+    e = getenv("ELFHIP_NET_SPLIT_SKIP");
+    if (e) n->split_skip = atoi(e) != 0;
   }
   int rc = n->alloc();
   if (rc != ELFHIP_OK) { delete n; return rc; }

@@ -1,5 +1,5 @@
 """Generate tests/golden/net_*.npz: (input, pi, V) of the fp32 PyTorch-CPU restatement of
-Model_PolicyValue (oracle/model_ref.py) with seeded random weights.  The weights themselves are NOT
+Model_PolicyValue (oracle/model_ref.py) with seeded random weights (the seed is stored in the file).  The weights themselves are NOT
 stored (they are regenerated from the seed in the test); inputs are real feature planes of seeded
 random checkers games (oracle) or random {0,1} planes (Go-shaped).  Run: python tests/golden/gen_net.py"""
 import os
@@ -18,6 +18,7 @@ CONFIGS = {
     "checkers_10x128": dict(planes=36, board=8, dim=128, num_block=10, num_action=170),
     "go_2x32": dict(planes=18, board=19, dim=32, num_block=2, num_action=362),
     "go_4x224": dict(planes=18, board=19, dim=224, num_block=4, num_action=362),
+    "go_20x224": dict(planes=18, board=19, dim=224, num_block=20, num_action=362),   # BASELINE.json configs[3]
 }
 
 
@@ -39,20 +40,33 @@ def checkers_inputs(n, seed):
 
 def main():
     torch.set_num_threads(8)
+    only = sys.argv[1:]
     for name, cfg in CONFIGS.items():
-        n = 24 if cfg["board"] == 8 else 6
+        if only and name not in only:
+            continue
+        n = 24 if cfg["board"] == 8 else (4 if cfg["num_block"] >= 20 else 6)
         if cfg["board"] == 8:
             x = checkers_inputs(n, 5)
         else:
             x = (np.random.default_rng(7).random((n, cfg["planes"], 19, 19)) < 0.3).astype(np.float32)
-        m = seeded_model(seed=0, **cfg)
-        with torch.no_grad():
-            o = m(torch.from_numpy(x))
+        # seeded random weights leave a head's single channel dead (ReLU output 0 everywhere) for many seeds, and a
+        # dead head's output does not depend on the trunk at all: take the first seed whose two heads are both alive
+        for seed in range(64):
+            m = seeded_model(seed=seed, **cfg)
+            with torch.no_grad():
+                xt = torch.from_numpy(x)
+                t = m.resnet(m.init_conv(xt))
+                alive = min(float((m.pi_final_conv(t) > 0).float().mean()), float((m.value_final_conv(t) > 0).float().mean()))
+                o = m(xt)
+            if alive >= 0.3:
+                break
+        else:
+            raise SystemExit("no seed with live heads for " + name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "net_%s.npz" % name),
                             x=np.packbits(x.astype(np.uint8), axis=None), x_shape=np.array(x.shape),
-                            pi=o["pi"].numpy(), V=o["V"].numpy(), cfg=np.array([cfg[k] for k in ("planes", "board", "dim", "num_block", "num_action")]),
-                            meta=np.array(["torch %s CPU fp32; oracle/model_ref.py seeded_model(seed=0)" % torch.__version__]))
-        print(name, x.shape, float(o["pi"].max()), float(o["V"].abs().max()))
+                            pi=o["pi"].numpy(), V=o["V"].numpy(), seed=np.array(seed), cfg=np.array([cfg[k] for k in ("planes", "board", "dim", "num_block", "num_action")]),
+                            meta=np.array(["torch %s CPU fp32; oracle/model_ref.py seeded_model(seed=%d)" % (torch.__version__, seed)]))
+        print(name, "seed", seed, x.shape, float(o["pi"].max()), float(o["V"].abs().max()))
 
 
 if __name__ == "__main__":

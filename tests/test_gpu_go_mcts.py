@@ -210,3 +210,26 @@ def test_go_leaf_features_follow_the_path(torch_cuda):
         depth_seen = step
         ts.backup(torch.tensor(pi, device="cuda"), torch.zeros(n, dtype=torch.float32, device="cuda"))
     assert depth_seen == 11
+
+
+def test_go_configs3_search_1600_rollouts_scripted_policy(torch_cuda):
+    """BASELINE.json configs[3]'s search shape: 1,600 rollouts per move, 8 leaves per batch, virtual loss 1, persistent
+    tree over three moves (the kept subtrees reach ~2,500 nodes under this peaked scripted policy)."""
+    _play(torch_cuda, 3, 3, dict(num_rollouts_per_thread=1600, num_rollouts_per_batch=8, virtual_loss=1, c_puct=1.5),
+          policy_kind=1, seed=7, start_plies=40, max_nodes=6000, max_edges=6000 * 330)
+
+
+def test_go_configs3_search_with_the_bench_arena_sizing(torch_cuda):
+    """The same search with bench.py's arena sizing (max_nodes = R + R/2 + 64, 300 edges per node) and the flat
+    (uniform) evaluator, whose kept subtrees are as small as the random-weight network's."""
+    R = 1600
+    _play(torch_cuda, 2, 3, dict(num_rollouts_per_thread=R, num_rollouts_per_batch=8, virtual_loss=1, c_puct=1.5),
+          policy_kind=0, seed=13, start_plies=40, max_nodes=R + R // 2 + 64, max_edges=(R + R // 2 + 64) * 300)
+
+
+def test_go_tree_advance_in_chunks_of_spare_arenas(torch_cuda, monkeypatch):
+    """treeAdvance with fewer spare arenas than trees (as on a full GPU): chunks of two trees per launch, the
+    arenas change owners from chunk to chunk, the trees stay the oracle's."""
+    monkeypatch.setenv("ELFHIP_MCTS_SPARE_ARENAS", "2")
+    _play(torch_cuda, 5, 4, dict(num_rollouts_per_thread=48, num_rollouts_per_batch=8, virtual_loss=1, c_puct=1.5),
+          policy_kind=1, seed=19, start_plies=50, max_nodes=512, max_edges=160000)

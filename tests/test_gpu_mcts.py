@@ -149,6 +149,13 @@ def test_scripted_network_split_path_batch8_and_options(torch_cuda):
                 policy_kind=1, seed=6, start_plies=6)
 
 
+def test_tree_advance_in_chunks_of_spare_arenas(torch_cuda, monkeypatch):
+    """fewer spare arenas than trees: treeAdvance runs in chunks and the arenas change owners (mcts_core.h)"""
+    monkeypatch.setenv("ELFHIP_MCTS_SPARE_ARENAS", "5")
+    _play_games(torch_cuda, 12, 8, dict(num_rollouts_per_thread=64, num_rollouts_per_batch=8, virtual_loss=1, c_puct=1.5),
+                policy_kind=1, seed=21, start_plies=8)
+
+
 def test_late_game_terminal_nodes(torch_cuda):
     """Start deep in the game so searches reach terminal positions (value +-1, no edges)."""
     _play_games(torch_cuda, 24, 14, dict(num_rollouts_per_thread=64, num_rollouts_per_batch=2, virtual_loss=1, c_puct=1.5),
