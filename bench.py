@@ -49,13 +49,16 @@ def cpu_baseline(threads=16, boards_per_thread=256, plies=8192):
                       % (threads, boards_per_thread, plies, dt)}
 
 
-def nn_rollouts_leg(games, steps, warmup, local, world, barrier):
+def nn_rollouts_leg(games, moves, local, world, barrier):
     """Second half of BASELINE.json's metric: NN-evaluated MCTS rollouts/s on configs[3] (Go 19x19 self-play,
     4,096 games per GPU, 1,600 rollouts/move, 8 leaves per batch, virtual loss 1, 20-block x 224 ResNet in bf16
-    MFMA, seeded random weights).  One step = one search batch over all games: select (descents + Go moves +
-    18 planes) -> network forward on games*8 leaves -> backup.  Only leaves that went through the network count."""
+    MFMA, seeded random weights), measured over WHOLE moves: set roots, 200 search batches (select: descents + Go
+    moves + 18 planes -> the rows that need the network are gathered into a dense batch -> forward -> replies
+    scattered back -> backup), pick the most visited move, play it, treeAdvance.  Only leaves that went through the
+    network count; duplicate leaves of a batch and terminal leaves cost no network time."""
+    import numpy as np
     import torch
-    import torch.distributed as dist
+    from elf_amd._lib import check
     from elf_amd.boards import BoardBatch, GO19
     from elf_amd.mcts import TreeSearchBatch
     from elf_amd.net import PolicyValueNet, random_state_dict
@@ -69,56 +72,84 @@ def nn_rollouts_leg(games, steps, warmup, local, world, barrier):
     cfg = dict(planes=18, board=19, dim=dim, num_block=blocks, num_action=362)
     net = PolicyValueNet(max_batch=n * B, device=local, **cfg)
     net.load_state_dict(random_state_dict(seed=0, **cfg))
-    assert ts.set_roots(bb).cpu().numpy().all()
-    feat = torch.empty((n * B, 18, 19, 19), dtype=torch.float32, device="cuda")
+    S = n * B
+    feat = torch.empty((S, 18, 19, 19), dtype=torch.float32, device="cuda")
+    cfeat = torch.empty_like(feat)
     need = torch.empty((n, B), dtype=torch.uint8, device="cuda")
-    pi = torch.empty((n * B, 362), dtype=torch.float32, device="cuda")
-    v = torch.empty((n * B, 1), dtype=torch.float32, device="cuda")
+    pi = torch.zeros((S, 362), dtype=torch.float32, device="cuda")
+    v = torch.zeros((S, 1), dtype=torch.float32, device="cuda")
+    cpi = torch.empty_like(pi)
+    cv = torch.empty_like(v)
     L = ts.L
+    nbatch = (R + B - 1) // B
+    fwd_ev = []
+    rows = [0]
 
-    def step(ev=None):
-        if ev: ev[0].record()
-        L.elfhip_mcts_select(ts.h, None, feat.data_ptr(), need.data_ptr())
-        if ev: ev[1].record()
-        L.elfhip_net_forward(net.h, feat.data_ptr(), n * B, pi.data_ptr(), None, v.data_ptr())
-        if ev: ev[2].record()
-        L.elfhip_mcts_backup(ts.h, pi.data_ptr(), v.data_ptr())
-        if ev: ev[3].record()
+    def search_batch(timed):
+        check(L.elfhip_mcts_select(ts.h, None, feat.data_ptr(), need.data_ptr()))
+        idx = torch.nonzero(need.view(-1)).to(torch.int32).view(-1)     # rows that need the network (index plumbing only)
+        k = int(idx.numel())
+        if k:
+            check(L.elfhip_gather_rows(feat.data_ptr(), 18 * 361 * 4, idx.data_ptr(), k, cfeat.data_ptr(), local, None))
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(L.elfhip_net_forward(net.h, cfeat.data_ptr(), k, cpi.data_ptr(), None, cv.data_ptr()))
+            if timed:
+                e1.record()
+                fwd_ev.append((e0, e1))
+                rows[0] += k
+            check(L.elfhip_scatter_rows(cpi.data_ptr(), 362 * 4, idx.data_ptr(), k, pi.data_ptr(), local, None))
+            check(L.elfhip_scatter_rows(cv.data_ptr(), 4, idx.data_ptr(), k, v.data_ptr(), local, None))
+        check(L.elfhip_mcts_backup(ts.h, pi.data_ptr(), v.data_ptr()))
 
-    for _ in range(warmup):
-        step()
+    def one_move(timed):
+        assert ts.set_roots(bb).cpu().numpy().all()
+        for _ in range(nbatch):
+            search_batch(timed)
+        best = ts.result()["best"]
+        bb.forward(best)
+        ts.treeAdvance(best)
+
+    for _ in range(2):                           # warm-up: two search batches, then fresh trees again
+        assert ts.set_roots(bb).cpu().numpy().all()
+        search_batch(False)
+    ts.clear()
     barrier()
     s0, _ = ts.stats()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
     barrier()
     t0 = time.perf_counter()
-    for k in range(steps):
-        step(evs[k])
+    for _ in range(moves):
+        one_move(True)
     barrier()
     dt = time.perf_counter() - t0
     s1, flags = ts.stats()
     evals = s1["evals"] - s0["evals"]
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([evals], dtype=torch.int64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    sel = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
-    fwd = sum(e[1].elapsed_time(e[2]) for e in evs) / steps
-    bak = sum(e[2].elapsed_time(e[3]) for e in evs) / steps
+    rollouts = s1["rollouts"] - s0["rollouts"]
+    depth = (s1["depth_sum"] - s0["depth_sum"]) / max(1, rollouts)
+    fwd_ms = sum(a.elapsed_time(b) for a, b in fwd_ev)
     macs = 361 * (9 * 18 * dim + blocks * 2 * 9 * dim * dim + 2 * dim) + 361 * 362 + 361 * 256 + 256
-    tf = 2.0 * macs * n * B / (fwd * 1e-3) / 1e12
-    return {"metric": "go_nn_evaluated_mcts_rollouts_per_sec", "value": int(tot.item()) / float(tmax.item()), "unit": "rollouts/s",
-            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": float(tmax.item()) / steps * 1e3, "dtype": "bf16",
+    tf = 2.0 * macs * rows[0] / (fwd_ms * 1e-3) / 1e12
+    return {"evals": evals, "rollouts": rollouts, "dt": dt, "mean_depth": depth, "fwd_ms": fwd_ms, "rows": rows[0], "tf": tf,
+            "parked": int((flags != 0).sum().item()), "macs": macs, "moves": moves, "nbatch": nbatch,
+            "bytes_per_tree": ts.bytes_per_tree() if hasattr(ts, "bytes_per_tree") else None,
+            "cfg": (n, R, B, blocks, dim)}
+
+
+def nn_rollouts_line(r, evals_all, dt_all, world):
+    n, R, B, blocks, dim = r["cfg"]
+    return {"metric": "go_nn_evaluated_mcts_rollouts_per_sec", "value": evals_all / dt_all, "unit": "rollouts/s",
+            "n_gpus": world, "steps": r["moves"], "warmup": 0, "ms_per_step": dt_all / r["moves"] * 1e3, "dtype": "bf16",
             "data": "synthetic", "scaling": "weak",
             "config": {"workload": "Go 19x19 self-play, %d games per GPU, %d rollouts/move, %d leaves/batch, vloss 1, %d-block x %d "
-                                   "ResNet bf16 (BASELINE.json configs[3]); one step = one search batch over all games"
-                                   % (n, R, B, blocks, dim)},
-            "time_split_ms": {"select_expand_planes": sel, "network": fwd, "backup": bak},
-            "parked_trees": int((flags != 0).sum().item()),
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None,
-                         "kernel": "conv3x3_board_kernel<224,19,1> (41 launches per forward)", "kernel_ms": fwd,
-                         "gflop_per_position": 2.0 * macs / 1e9, "positions_per_sec": n * B / (fwd * 1e-3)}}
+                                   "ResNet bf16 (BASELINE.json configs[3]); one step = one WHOLE move: %d search batches + pick + "
+                                   "play + treeAdvance" % (n, R, B, blocks, dim, r["nbatch"])},
+            "rollouts_per_step": r["rollouts"] // r["moves"], "evaluated_fraction": r["evals"] / max(1, r["rollouts"]),
+            "mean_depth": r["mean_depth"], "network_share_of_time": r["fwd_ms"] * 1e-3 / r["dt"],
+            "parked_trees": r["parked"], "tree_bytes": r["bytes_per_tree"],
+            "roofline": {"bound": "mfma", "achieved": r["tf"], "peak": 2500.0, "unit": "TFLOP/s", "frac": r["tf"] / 2500.0, "traffic": None,
+                         "kernel": "conv3x3_board_kernel<224,19,1,*> (41 launches per forward)", "kernel_ms": r["fwd_ms"] / max(1, r["moves"] * r["nbatch"]),
+                         "gflop_per_position": 2.0 * r["macs"] / 1e9, "positions_per_sec": r["rows"] / (r["fwd_ms"] * 1e-3)}}
 
 
 def main():
@@ -131,7 +162,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nn-rollouts", action="store_true", help="skip the configs[3] leg (NN-evaluated MCTS rollouts/s)")
     ap.add_argument("--nn-games", type=int, default=4096)
-    ap.add_argument("--nn-steps", type=int, default=6)
+    ap.add_argument("--nn-moves", type=int, default=1, help="whole 1,600-rollout moves timed by the configs[3] leg")
     args = ap.parse_args()
 
     import torch
@@ -192,11 +223,27 @@ def main():
     # free the playout slab before the self-play leg (it needs ~160 GB of tree arenas and activations)
     del bb
     nn = None
+    nn_failed = False
     if not args.no_nn_rollouts:
+        # A rank that fails must not leave the others waiting inside a collective: the leg itself runs no
+        # collective; every rank then takes part in the same reductions whatever happened to it.
+        r, err = None, None
+        barrier()
         try:
-            nn = nn_rollouts_leg(args.nn_games, args.nn_steps, 2, local, world, barrier)
-        except Exception as e:   # the headline line must not be lost to the secondary leg
-            nn = {"metric": "go_nn_evaluated_mcts_rollouts_per_sec", "value": None, "error": "%s: %s" % (type(e).__name__, e)}
+            r = nn_rollouts_leg(args.nn_games, args.nn_moves, local, world, barrier if world == 1 else torch.cuda.synchronize)
+        except Exception as e:
+            err = "%s: %s" % (type(e).__name__, e)
+        red = torch.tensor([1.0 if r else 0.0, r["dt"] if r else 0.0, float(r["evals"]) if r else 0.0], dtype=torch.float64, device="cuda")
+        ok, tmx, tot_e = red[0:1].clone(), red[1:2].clone(), red[2:3].clone()
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot_e, op=dist.ReduceOp.SUM)
+        if ok.item() > 0:
+            nn = nn_rollouts_line(r, float(tot_e.item()), float(tmx.item()), world)
+        else:   # the headline line is still printed, the process then exits non-zero
+            nn = {"metric": "go_nn_evaluated_mcts_rollouts_per_sec", "value": None, "error": err or "failed on another rank"}
+            nn_failed = True
     if rank == 0:
         moves_per_launch = moves / max(1, args.steps)
         achieved = ALGO_BYTES_PER_MOVE * moves_per_launch / (kern_ms * 1e-3) / 1e9
@@ -229,6 +276,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if nn_failed:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -389,6 +389,12 @@ int elfhip_mcts_advance(elfhip_mcts* h, const int16_t* d_actions) {
   return h->m->advance(d_actions);
 }
 
+long long elfhip_mcts_tree_bytes(const elfhip_mcts* h, int* h_n_arenas) {
+  if (!h || !h->m) { elfhip_set_error("mcts_tree_bytes: null handle"); return ELFHIP_EINVAL; }
+  if (h_n_arenas) *h_n_arenas = h->m->d.n_arenas;
+  return (long long)h->m->bytes_per_tree();
+}
+
 int elfhip_mcts_stats(elfhip_mcts* h, unsigned long long* h_stats4, int32_t* d_flags) {
   CHECK_M(h);
   mcts::MctsBase* m = h->m;

@@ -141,3 +141,12 @@ class TreeSearchBatch:
         fl = torch.empty(self.n, dtype=torch.int32, device=self.device)
         check(self.L.elfhip_mcts_stats(self.h, st, fl.data_ptr()))
         return dict(rollouts=st[0], evals=st[1], depth_sum=st[2], edge_sum=st[3]), fl
+
+    def bytes_per_tree(self):
+        """Device bytes of one tree arena (elfhip_mcts_tree_bytes); the handle holds `arenas()` of them."""
+        return int(self.L.elfhip_mcts_tree_bytes(self.h, None))
+
+    def arenas(self):
+        k = C.c_int()
+        check(self.L.elfhip_mcts_tree_bytes(self.h, C.byref(k)))
+        return k.value

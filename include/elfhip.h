@@ -225,6 +225,11 @@ int elfhip_mcts_advance(elfhip_mcts* m, const int16_t* d_actions);
  * created} (nullable); d_flags (nullable) i32 [n_trees]: non-zero = tree parked (1 node arena full,
  * 2 edge arena full, 4 depth, 8 too many legal moves, 16 root mismatch).  Synchronises. */
 int elfhip_mcts_stats(elfhip_mcts* m, unsigned long long* h_stats4, int32_t* d_flags);
+/* Device bytes one tree's arena takes (node records + node states + edges) with this handle's max_nodes /
+ * max_edges; the handle holds n_trees + n_spare such arenas (n_spare = n_trees up to 1,024 trees, else
+ * max(1024, n_trees / 8): treeAdvance's destinations).  No reference counterpart (its nodes live on the heap):
+ * a sizing aid for callers that fill a GPU with trees.  h_n_arenas (nullable) receives the arena count. */
+long long elfhip_mcts_tree_bytes(const elfhip_mcts* m, int* h_n_arenas);
 
 /* ------------------------------------------------------------------------------------------------
  * Policy/value network forward (eval mode), bf16 MFMA with fp32 accumulation.
