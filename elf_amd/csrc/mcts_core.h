@@ -656,6 +656,9 @@ struct MctsBase {
     }
     if (opt->max_nodes > 0 && opt->max_nodes < 2) { elfhip_set_error("mcts_create: max_nodes=%d", opt->max_nodes); return ELFHIP_EINVAL; }
     d.max_nodes = opt->max_nodes > 0 ? opt->max_nodes : 8 * o.R + 64;
+    if (opt->max_nodes <= 0) {   // tests: a small arena behind callers that pass no size (the pybind facade)
+      if (const char* e = getenv("ELFHIP_MCTS_MAX_NODES")) { const int v = atoi(e); if (v >= 2 && v <= MAX_NODES_LIMIT) d.max_nodes = v; }
+    }
     if (d.max_nodes > MAX_NODES_LIMIT) d.max_nodes = MAX_NODES_LIMIT;
     d.max_edges = opt->max_edges > 0 ? opt->max_edges : default_edges_per_node * d.max_nodes;
     // spare arenas for treeAdvance: every tree at once while that is cheap, an eighth of the trees (eight launches

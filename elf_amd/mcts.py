@@ -110,6 +110,37 @@ class TreeSearchBatch:
             r["policy_visits"] = pol
         return r
 
+    OVERFLOW_FLAGS = 1 | 2 | 4 | 8     # node arena, edge arena, depth, legal-move list (mcts_core.h FLAG_*)
+
+    def parked(self):
+        """[n] uint8: trees a launch parked because an arena (or a fixed-size list) was full.  A parked tree is
+        skipped by every later launch until it is cleared; search_with_recovery() is the driver-side answer."""
+        return (self.stats()[1] & self.OVERFLOW_FLAGS).ne(0).to(torch.uint8)
+
+    def search_with_recovery(self, boards, search):
+        """Run `search()` (the rollouts of one move; roots already set) and, where it parked trees, give those
+        trees a second, fresh search: the reference's heap never fills, here a persistent tree that outgrew its
+        arena is cleared (that move is then searched without the carried-over subtree - the one deviation, counted
+        in `self.arena_restarts`) instead of stalling its game.  A tree that parks again even when fresh cannot fit
+        one move's rollouts: ElfHipError."""
+        search()
+        p = self.parked()
+        if not bool(p.any()):
+            return 0
+        k = int(p.sum().item())
+        self.arena_restarts = getattr(self, "arena_restarts", 0) + k
+        self.clear(p)
+        self.set_active(p)
+        try:
+            self.set_roots(boards)
+            search()
+        finally:
+            self.set_active(None)
+        if bool(self.parked().any()):
+            raise _lib.ElfHipError("tree search: %d tree(s) overflow their arena even from an empty tree "
+                                   "(max_nodes / max_edges too small for num_rollouts_per_thread)" % int(self.parked().sum().item()))
+        return k
+
     def set_active(self, active=None):
         """only trees with active[t] != 0 take part in set_roots / select / backup / picks until the next call
         (the AI that owns the move, ClientGameSelfPlay.cc:344-346); None = all"""

@@ -315,6 +315,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
           break;
         }
         case MOVE:
+          if (recover_parked_trees()) { phase_ = SELECT; break; }   // a second, fresh search for trees whose arena filled up
           { PhaseClock::Scope sc(clock_.ms[4]); make_moves(); }
           phase_ = BEGIN;
           break;
@@ -472,6 +473,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
     }
     py::dict d;
     d["rollouts"] = st[0]; d["evals"] = st[1]; d["depth_sum"] = st[2]; d["edge_sum"] = st[3];
+    d["arena_restarts"] = arena_restarts_;
     py::dict h;  // where the host loop's wall time went since start (each phase includes the GPU waits inside it)
     h["select"] = clock_.ms[0]; h["serve"] = clock_.ms[1]; h["reply"] = clock_.ms[2]; h["backup"] = clock_.ms[3];
     h["move"] = clock_.ms[4]; h["begin"] = clock_.ms[5];
@@ -608,7 +610,38 @@ class SelfPlayEngine : public elfhip_py::Engine {
 
   // One move of every game (ClientGameSelfPlay::act, :249-375): who moves (human / which AI / policy only),
   // roots, root noise, and the list of search jobs that the SELECT phase works through.
+  // A launch parks a tree whose node / edge arena (or depth / legal-move list) is full: every later launch skips
+  // it, so left alone its game would never get a move.  The reference's heap never fills; here such a tree is
+  // cleared and searched again from its root alone (that one move without the subtree the persistent tree carried
+  // over - counted in searchStats()["arena_restarts"]).  A tree that parks again even when fresh cannot hold one
+  // move's rollouts: that is a configuration error and raises.
+  bool recover_parked_trees() {
+    bool again = false;
+    for (int k = 0; k < n_ai_; ++k) {
+      ck(elfhip_mcts_stats(mcts_[k], nullptr, (int32_t*)d_nedges_), "mcts_stats");
+      hk(hipMemcpy(h_nedges_.data(), d_nedges_, (size_t)n_ * 4, hipMemcpyDeviceToHost), "copy flags");
+      std::vector<uint8_t> parked(n_, 0);
+      int cnt = 0;
+      for (int i = 0; i < n_; ++i) if (h_nedges_[i] & 15) { parked[i] = 1; ++cnt; }
+      if (!cnt) continue;
+      if (recovering_)
+        throw std::runtime_error("tree search: " + std::to_string(cnt) + " tree(s) overflow their arena even from an empty tree "
+                                 "(num_rollouts_per_thread too large for the tree arena)");
+      arena_restarts_ += cnt;
+      if (!again) { jobs_.clear(); job_ = 0; rollouts_ = 0; }
+      hk(hipMemcpy(d_m8_, parked.data(), (size_t)n_, hipMemcpyHostToDevice), "copy mask");
+      ck(elfhip_mcts_clear(mcts_[k], (const uint8_t*)d_m8_), "mcts_clear");
+      set_active(k, parked);
+      ck(elfhip_mcts_set_roots(mcts_[k], boards_, nullptr), "mcts_set_roots");
+      jobs_.push_back(Job{k, parked, spec_[k].R});
+      again = true;
+    }
+    recovering_ = again;
+    return again;
+  }
+
   void begin_move() {
+    recovering_ = false;
     jobs_.clear(); job_ = 0; rollouts_ = 0;
     bool any_human = false, any_ponly = false;
     for (int i = 0; i < n_; ++i) {
@@ -625,7 +658,10 @@ class SelfPlayEngine : public elfhip_py::Engine {
       std::vector<uint8_t> own(n_), search(n_), fresh(n_, 0);
       for (int i = 0; i < n_; ++i) { own[i] = (!h_human_[i] && h_owner_[i] == k) ? 1 : 0; search[i] = own[i] && !h_ponly_[i]; }
       set_active(k, own);
-      ck(elfhip_mcts_set_roots(mcts_[k], boards_, nullptr), "mcts_set_roots");
+      ck(elfhip_mcts_set_roots(mcts_[k], boards_, (uint8_t*)d_ok_), "mcts_set_roots");
+      hk(hipMemcpy(h_ok_.data(), d_ok_, (size_t)n_, hipMemcpyDeviceToHost), "copy ok");
+      for (int i = 0; i < n_; ++i)
+        if (own[i] && !h_ok_[i]) throw std::range_error("Root state is not the same (game " + std::to_string(i) + ")");  // tree_search.h:582
       if (any_ponly) {  // runPolicyOnly evaluates the root only if the persistent tree has not visited it yet
         ck(elfhip_mcts_result(mcts_[k], nullptr, nullptr, nullptr, nullptr, (int32_t*)d_nedges_, nullptr, nullptr, nullptr, nullptr, 0,
                               nullptr), "mcts_result");
@@ -762,7 +798,9 @@ class SelfPlayEngine : public elfhip_py::Engine {
     int nfin = 0;
     for (int i = 0; i < n_; ++i) {
       if (h_force_end_[i]) { h_term_[i] = 1; ++nfin; continue; }   // the human ended the game: finish_game without a move
-      if (h_move_[i] < 0 || !h_ok_[i]) { h_term_[i] = 0; continue; }  // no move this round / "Move cannot be applied": logged, goes on
+      if (h_move_[i] < 0 && !h_human_[i])   // every root is a live position: a search that yields no move is a bug, not a pass
+        throw std::runtime_error("self-play: game " + std::to_string(i) + " got no move from the search");
+      if (h_move_[i] < 0 || !h_ok_[i]) { h_term_[i] = 0; continue; }  // a human who has not answered / "Move cannot be applied": logged, goes on
       const bool diverse = pre_ply[i] <= go_.policy_distri_cutoff;
       cur_[i].moves.push_back(h_move_[i]);
       if (!h_human_[i]) cur_[i].values.push_back(h_val_[i]);       // mcts_update_info; a human move records no value
@@ -801,6 +839,8 @@ class SelfPlayEngine : public elfhip_py::Engine {
   GameOptions go_;
   elfhip_game_info gi_{};
   int device_ = 0, n_ = 0, max_chunk_ = 1, n_ai_ = 1, slotB_ = 0, human_for_ = 0;
+  bool recovering_ = false;
+  long long arena_restarts_ = 0;
   size_t feat_row_ = 0;
   elfhip_boards* boards_ = nullptr;
   elfhip_mcts* mcts_[2] = {nullptr, nullptr};

@@ -46,11 +46,10 @@ class SelfPlayBatch:
     def step(self):
         """One move of every game.  Returns the number of games that finished."""
         ts, bb = self.ts, self.bb
-        ts.set_roots(bb)
-        if self.net is None:
-            ts.run_uniform()
-        else:
-            ts.run(self._evaluate)
+        ok = ts.set_roots(bb)
+        if not bool(ok.all()):   # TreeSearchT::setRootNodeState: "Root state is not the same" (tree_search.h:582)
+            raise _lib.ElfHipError("tree search: the stored root of %d tree(s) differs from the game state" % int((ok == 0).sum().item()))
+        ts.search_with_recovery(bb, ts.run_uniform if self.net is None else (lambda: ts.run(self._evaluate)))
         check(ts.L.elfhip_mcts_pick_moves(ts.h, self.ply.data_ptr(), self.cutoff, self.seed, self.counter,
                                           self._move.data_ptr(), self._pol.data_ptr() if self._pol is not None else None,
                                           self._val.data_ptr()))
@@ -60,6 +59,8 @@ class SelfPlayBatch:
         self.values[idx, self.nmoves] = self._val
         if self.policies is not None:
             self.policies[idx, self.nmoves] = self._pol
+        if bool((self._move < 0).any()):   # every root is a live position: a search that yields no move is a bug, not a pass
+            raise _lib.ElfHipError("self-play: %d game(s) got no move from the search" % int((self._move < 0).sum().item()))
         ok = bb.forward(self._move)
         ts.treeAdvance(self._move)
         okl = ok.to(torch.int64)

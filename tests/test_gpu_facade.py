@@ -141,6 +141,26 @@ def test_facade_failed_step_keeps_running():
     w.stop()
 
 
+def test_facade_goes_on_past_an_arena_overflow(monkeypatch):
+    """ELFHIP_MCTS_MAX_NODES (test hook) gives the facade's trees an arena that one move's rollouts fit but a
+    persistent tree outgrows: parked trees get a second, fresh search and every game still ends."""
+    monkeypatch.setenv("ELFHIP_MCTS_MAX_NODES", "72")
+    n = 16
+    GC, w = _context(n, 64, rollouts=64, rpb=8)
+    w.reg_callback("actor_black", _uniform)
+    w.reg_callback("actor_white", _uniform)
+    w.reg_callback("game_end", lambda batch, bs: None)
+    w.start()
+    for _ in range(400000):
+        w.run()
+        if GC.getClient().getGameStats().getWinRateStats().total_games >= n:
+            break
+    st = GC.searchStats()
+    assert GC.getClient().getGameStats().getWinRateStats().total_games >= n
+    assert st["arena_restarts"] > 0
+    w.stop()
+
+
 @pytest.mark.parametrize("game", ["russian", "ugolki"])
 def test_facade_other_games_match_oracle_search(game):
     """_elfgames_russian_checkers / _elfgames_ugolki: one game each through wait/step with a scripted

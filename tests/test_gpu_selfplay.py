@@ -98,3 +98,31 @@ def test_selfplay_with_network_and_diverse_moves_runs():
     # different seeds diversify the openings
     first = sp.moves[:, 0].cpu().numpy()
     assert len(np.unique(first)) > 1
+
+
+def test_selfplay_goes_on_past_an_arena_overflow():
+    """An arena that holds one move's rollouts but not the subtrees a persistent tree carries along: launches park
+    the trees that fill it; the driver clears those and searches them again instead of stalling their games."""
+    from elf_amd import _lib
+    from elf_amd.boards import AMERICAN
+    from elf_amd.selfplay import SelfPlayBatch
+    n = 32
+    sp = SelfPlayBatch(AMERICAN, n, num_rollouts_per_thread=64, num_rollouts_per_batch=8, virtual_loss=1, c_puct=1.5,
+                       max_nodes=72, max_edges=72 * 14)
+    for _ in range(300):
+        sp.step()
+        if sp.win_stats["total_games"] >= n:
+            break
+    assert sp.win_stats["total_games"] >= n                       # every slot finished a game: nothing stalled
+    assert getattr(sp.ts, "arena_restarts", 0) > 0                # and the overflow did happen
+    assert not bool(sp.ts.parked().any())
+    for slab in sp.take_records():
+        for i in range(len(slab["game_id"])):
+            nm = int(slab["n_moves"][i])
+            assert nm > 0 and (slab["moves"][i][:nm] >= 0).all()
+    # an arena that cannot hold even a fresh search is a configuration error, reported as such
+    tiny = SelfPlayBatch(AMERICAN, 4, num_rollouts_per_thread=64, num_rollouts_per_batch=8, virtual_loss=1, c_puct=1.5,
+                         max_nodes=16, max_edges=16 * 14)
+    with pytest.raises(_lib.ElfHipError):
+        for _ in range(10):
+            tiny.step()
