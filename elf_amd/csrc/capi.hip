@@ -3,11 +3,14 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 #include "common.h"
 #include "stdorder.h"
-#include <vector>
 
 #include <mutex>
+#include <random>
+
+struct elfhip_rng { std::vector<std::mt19937> g; };
 
 static thread_local char g_err[512] = "";
 
@@ -92,7 +95,28 @@ extern "C" {
 
 const char* elfhip_last_error(void) { return g_err; }
 
-int elfhip_abi_version(void) { return 1; }
+int elfhip_abi_version(void) { return 2; }
+
+int elfhip_rng_create(int n, const uint32_t* h_seeds, elfhip_rng** out) {
+  if (n < 1 || !out) { elfhip_set_error("rng_create: bad arguments"); return ELFHIP_EINVAL; }
+  elfhip_rng* r = new (std::nothrow) elfhip_rng();
+  if (!r) { elfhip_set_error("rng_create: host allocation failed"); return ELFHIP_ENOMEM; }
+  r->g.resize((size_t)n);
+  for (int i = 0; i < n; ++i) r->g[(size_t)i].seed(h_seeds ? h_seeds[i] : 0u);
+  *out = r;
+  return ELFHIP_OK;
+}
+int elfhip_rng_destroy(elfhip_rng* r) { delete r; return ELFHIP_OK; }
+int elfhip_rng_next_u32(elfhip_rng* r, const uint8_t* h_which, uint32_t* h_out) {
+  if (!r || !h_out) { elfhip_set_error("rng_next_u32: null argument"); return ELFHIP_EINVAL; }
+  for (size_t i = 0; i < r->g.size(); ++i) if (!h_which || h_which[i]) h_out[i] = (uint32_t)r->g[i]();
+  return ELFHIP_OK;
+}
+int elfhip_rng_canonical(elfhip_rng* r, const uint8_t* h_which, double* h_out) {
+  if (!r || !h_out) { elfhip_set_error("rng_canonical: null argument"); return ELFHIP_EINVAL; }
+  for (size_t i = 0; i < r->g.size(); ++i) if (!h_which || h_which[i]) h_out[i] = std::generate_canonical<double, 53>(r->g[i]);
+  return ELFHIP_OK;
+}
 
 int elfhip_device_count(void) {
   int n = 0;

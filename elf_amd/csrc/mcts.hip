@@ -13,6 +13,7 @@
 // A tree is two ping-pong arenas in HBM (nodes + a struct-of-arrays edge pool; a node's edges are
 // contiguous and already stored in unordered_map iteration order, so the UCT scan is one coalesced
 // read); treeAdvance compacts the kept subtree into the other arena with a breadth-first copy.
+#include <cstring>
 #include "american_dev.h"
 #include "mcts_core.h"
 
@@ -219,6 +220,42 @@ mcts_search_kernel(TreeDev d, AmExtra x, Opt o, uint64_t* __restrict__ leaf_stat
   }
 }
 
+// Test hook (elfhip_test_find_move): a hand-built node in tree 0's arena - root VISITED with n edges, one child
+// record per edge that carries statistics - then ONE step of the product's own select_one.
+struct NoGame { __device__ static inline void on_new_child(const TreeDev&, TV&, int, int, int) {} };
+__global__ void __launch_bounds__(64)
+mcts_test_find_move_kernel(TreeDev d, Opt o, int n, const float* __restrict__ prior, const float* __restrict__ reward,
+                           const int* __restrict__ visits, const float* __restrict__ vloss, int flip, float mq, float pq, int nv,
+                           int* __restrict__ out) {
+  const int lane = threadIdx.x;
+  TV tv = tree_view(d, 0);
+  int nn = 1;
+  if (lane == 0) {
+    init_node(tv, 0, pq, -1, 0);
+    tv.meanQ[0] = mq; tv.visits[0] = nv;
+    tv.meta[0] = VISITED | (flip ? META_FLIP : 0u) | META_STATE_SET | ((uint32_t)n << 16);
+    for (int j = 0; j < n; ++j) {
+      int child = NOCHILD;
+      if (visits[j] != 0 || vloss[j] != 0.f || reward[j] != 0.f) {
+        child = nn++;
+        init_node(tv, child, 0.f, 0, j);
+        tv.in_r[child] = reward[j]; tv.in_n[child] = visits[j]; tv.in_l[child] = vloss[j];
+      }
+      *(uint2*)(tv.ep.p + (size_t)j * EDGE_BYTES) = make_uint2(__float_as_uint(prior[j]), (uint32_t)j | ((uint32_t)child << 16));
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  int flags = 0, depth = 0;
+  const int leaf = select_one<NoGame>(d, tv, o, 0, 0, lane, nn, flags, depth);
+  __syncthreads();
+  if (lane == 0) {
+    out[0] = (int)tv.paction[leaf];   // the edge index was stored as the action
+    out[1] = (int)__float_as_uint(tv.meanQ[0]);
+    out[2] = flags; out[3] = depth;
+  }
+}
+
 struct AmericanMcts : MctsBase {
   AmExtra x{};
   int alloc(int n_trees, const elfhip_ts_options* opt) {
@@ -358,13 +395,13 @@ int elfhip_mcts_result(elfhip_mcts* h, int16_t* d_best, int32_t* d_total_visits,
   return ELFHIP_OK;
 }
 
-int elfhip_mcts_pick_moves(elfhip_mcts* h, const int32_t* d_ply, int policy_distri_cutoff, uint64_t seed, uint64_t counter,
+int elfhip_mcts_pick_moves(elfhip_mcts* h, const int32_t* d_ply, int policy_distri_cutoff, const double* d_canonical,
                            int16_t* d_move, uint8_t* d_policy_u8, float* d_value) {
   CHECK_M(h);
   if (!d_move) { elfhip_set_error("mcts_pick_moves: null d_move"); return ELFHIP_EINVAL; }
   mcts::MctsBase* m = h->m;
   hipLaunchKernelGGL(mcts::mcts_pick_kernel, dim3(m->d.n_trees), dim3(64), 0, m->stream, m->d, m->num_actions, d_ply,
-                     policy_distri_cutoff, seed, counter, d_move, d_policy_u8, d_value);
+                     policy_distri_cutoff, d_canonical, d_move, d_policy_u8, d_value);
   HIPCHECK(hipGetLastError());
   return ELFHIP_OK;
 }
@@ -393,6 +430,45 @@ long long elfhip_mcts_tree_bytes(const elfhip_mcts* h, int* h_n_arenas) {
   if (!h || !h->m) { elfhip_set_error("mcts_tree_bytes: null handle"); return ELFHIP_EINVAL; }
   if (h_n_arenas) *h_n_arenas = h->m->d.n_arenas;
   return (long long)h->m->bytes_per_tree();
+}
+
+int elfhip_test_find_move(int n_edges, const float* h_prior, const float* h_reward, const int32_t* h_visits, const float* h_vloss,
+                          int flip, float mean_q, float parent_q, int num_visits, const elfhip_ts_options* opt, int device,
+                          int* h_best_edge, float* h_new_mean_q) {
+  if (n_edges < 1 || n_edges > 512 || !h_prior || !h_reward || !h_visits || !h_vloss || !opt || !h_best_edge || !h_new_mean_q) {
+    elfhip_set_error("test_find_move: bad arguments");
+    return ELFHIP_EINVAL;
+  }
+  elfhip_ts_options o = *opt;
+  o.num_rollouts_per_thread = 1; o.num_rollouts_per_batch = 1; o.virtual_loss = 0; o.persistent_tree = 1; o.pick_method = 0;
+  o.max_nodes = n_edges + 4; o.max_edges = n_edges + 4;
+  elfhip_mcts* h = nullptr;
+  int rc = elfhip_mcts_create(ELFHIP_AMERICAN, 1, &o, device, &h);
+  if (rc != ELFHIP_OK) return rc;
+  mcts::MctsBase* m = h->m;
+  float* d_f = nullptr; int* d_out = nullptr;
+  const size_t n = (size_t)n_edges;
+  hipError_t e = hipMalloc(&d_f, n * 16 + 16);
+  if (e == hipSuccess) {
+    d_out = (int*)(d_f + 4 * n);
+    e = hipMemcpy(d_f, h_prior, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_f + n, h_reward, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_f + 2 * n, h_visits, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_f + 3 * n, h_vloss, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(mcts_test_find_move_kernel, dim3(1), dim3(64), 0, m->stream, m->d, m->o, n_edges, d_f, d_f + n,
+                         (const int*)(d_f + 2 * n), d_f + 3 * n, flip, mean_q, parent_q, num_visits, d_out);
+      e = hipStreamSynchronize(m->stream);
+    }
+    int out[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, 16, hipMemcpyDeviceToHost);
+    *h_best_edge = out[0];
+    memcpy(h_new_mean_q, &out[1], 4);
+    (void)hipFree(d_f);
+  }
+  elfhip_mcts_destroy(h);
+  HIPCHECK(e);
+  return ELFHIP_OK;
 }
 
 int elfhip_mcts_stats(elfhip_mcts* h, unsigned long long* h_stats4, int32_t* d_flags) {

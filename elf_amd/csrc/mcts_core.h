@@ -445,10 +445,15 @@ mcts_result_kernel(TreeDev d, int NA, int pick, int16_t* __restrict__ best_out, 
 }
 
 // mcts_make_diverse_move / mcts_update_info (ClientGameSelfPlay.cc:94-122) + addMCTSPolicy
-// (GameStateExt.h:79-100) + MCTSPolicy::normalize (tree_search_base.h:251-262)
+// (GameStateExt.h:79-100) + MCTSPolicy::normalize / sampleAction (tree_search_base.h:251-269) +
+// elf_utils::sample_multinomial (elf/utils/utils.h:162-185).
+// canon[t] = the game rng's std::generate_canonical<double, 53> draw (what std::uniform_real_distribution<>
+// multiplies by its range): float rd = canon * Z with Z the float sum of the normalised policy in edge order; the
+// move is the first edge whose running float sum exceeds rd, the last edge when none does.
 static __global__ void __launch_bounds__(64)
-mcts_pick_kernel(TreeDev d, int NA, const int32_t* __restrict__ ply, int cutoff, uint64_t seed, uint64_t counter,
+mcts_pick_kernel(TreeDev d, int NA, const int32_t* __restrict__ ply, int cutoff, const double* __restrict__ canon,
                  int16_t* __restrict__ move, uint8_t* __restrict__ pol, float* __restrict__ value) {
+  __shared__ int s_vis[512];
   const int t = blockIdx.x, lane = threadIdx.x;
   if (d.t_flags[t] & FLAG_INACTIVE) return;  // the other AI's handle fills this game's outputs
   TV tv = tree_view(d, t);
@@ -462,6 +467,7 @@ mcts_pick_kernel(TreeDev d, int NA, const int32_t* __restrict__ ply, int cutoff,
   for (int base = 0; base < ne; base += 64) {
     const int j = base + lane;
     int v = j < ne ? edge_visits(tv, eb + j) : -1, vj = j < ne ? j : 0x7FFFFFFF, sum = j < ne ? v : 0;
+    if (j < ne && j < 512) s_vis[j] = v;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       int v2 = __shfl_xor(v, off), j2 = __shfl_xor(vj, off);
@@ -471,29 +477,29 @@ mcts_pick_kernel(TreeDev d, int NA, const int32_t* __restrict__ ply, int cutoff,
     if (v > bestv || (v == bestv && vj < bestj)) { bestv = v; bestj = vj; }
     total += sum;
   }
-  const bool diverse = ply && ply[t] <= cutoff && total > 0;
-  const uint64_t r = diverse ? elf_splitmix64(seed + (uint64_t)t * ELF_GOLDEN + counter) % (uint64_t)total : 0;
-  const float exp_sum = (float)total, maxp = total > 0 ? (float)bestv / exp_sum : 0.f;
-  int chosen = ne > 0 ? bestj : -1, cum = 0;
-  bool picked = false;
-  for (int base = 0; base < ne; base += 64) {
-    const int j = base + lane;
-    const int v = j < ne ? edge_visits(tv, eb + j) : 0;
-    if (pol && j < ne) {
-      const float p = (float)v / exp_sum;
+  __syncthreads();
+  const bool diverse = ply && canon && ply[t] <= cutoff && ne > 0;
+  const float exp_sum = (float)total, maxp = total > 0 ? (float)bestv / exp_sum : 0.f;   // visit counts sum exactly in float
+  if (pol) {
+    for (int j = lane; j < ne; j += 64) {
+      const float p = (float)s_vis[j] / exp_sum;
       const float q = p / maxp * 255.0f;
       pol[(size_t)t * NA + tv.ea[eb + j]] = total > 0 ? (uint8_t)q : 0;
     }
-    if (diverse && !picked) {
-      int incl = v;  // inclusive prefix sum over the wave
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) { int x = __shfl_up(incl, off); if (lane >= off) incl += x; }
-      const unsigned long long hit = __ballot(j < ne && (uint64_t)(cum + incl) > r);
-      if (hit) { chosen = base + (__ffsll((long long)hit) - 1); picked = true; }
-      cum += __shfl(incl, 63);
-    }
   }
   if (lane == 0) {
+    int chosen = ne > 0 ? bestj : -1;
+    if (diverse) {   // one lane: the two float sums are sequential in edge order
+      float Z = 0.0f;
+      for (int j = 0; j < ne; ++j) Z += (float)s_vis[j] / exp_sum;
+      const float rd = (float)(canon[t] * ((double)Z - 0.0) + 0.0);
+      float accu = 0.0f;
+      chosen = ne - 1;
+      for (int j = 0; j < ne; ++j) {
+        accu = (float)s_vis[j] / exp_sum + accu;
+        if (rd < accu) { chosen = j; break; }
+      }
+    }
     move[t] = chosen < 0 ? (int16_t)-1 : (int16_t)tv.ea[eb + chosen];
     if (value) value[t] = (ne == 0 || total == 0) ? tv.V[0] : edge_reward(tv, eb + bestj) / (float)edge_visits(tv, eb + bestj);
   }

@@ -334,6 +334,18 @@ class SelfPlayEngine : public elfhip_py::Engine {
     AnyP* pi = key(m, "pi");
     AnyP* v = key(m, "V");
     if (success && pi && v) {
+      // ReplyVersion (GameFeature.h:59-62) -> MCTSGameActor::post_nn_result (mcts/MCTSGameActor.h:222-229): an AI
+      // built for a model version (init_ai's required_version; -1 when the request is async) refuses a reply
+      // that another version produced
+      const long long need = req_.async ? -1 : spec_[jobs_[job_].ai].ver;
+      if (AnyP* rv = key(m, "rv"); rv && need >= 0 && rv->ptr && !rv->strides.empty()) {
+        std::vector<int64_t> ver((size_t)k);
+        hk(hipMemcpy2D(ver.data(), 8, rv->row(0), (size_t)rv->strides.at(0), 8, (size_t)k, hipMemcpyDefault), "copy rv");
+        for (int i = 0; i < k; ++i)
+          if (ver[(size_t)i] != need)
+            throw std::runtime_error("model version " + std::to_string(ver[(size_t)i]) + " and required version " +
+                                     std::to_string(need) + " are not consistent");
+      }
       // ReplyPolicy / ReplyValue (common/GameFeature.h:40-62): rows [0,k) of the caller's tensors
       copy_rows(d_cpi_, pi, A * 4, k, true, "copy pi");
       copy_rows(d_cv_, v, 4, k, true, "copy V");
@@ -573,6 +585,18 @@ class SelfPlayEngine : public elfhip_py::Engine {
       n_ai_ = 2;
       if (!req_.is_selfplay() && req_.player_swap) std::swap(spec_[0], spec_[1]);
     }
+    // GameBase::_rng (common/GameBase.h:43-49,76): one std::mt19937 per game for the life of the context, seeded
+    // with GameOptions.seed (every game the same, as in the reference); seed == 0 is time-based there, here a fixed
+    // per-game value
+    if ((int)game_rng_.size() != n_) {
+      game_rng_.resize((size_t)n_);
+      for (int i = 0; i < n_; ++i) game_rng_[(size_t)i].seed(go_.seed ? (uint32_t)go_.seed : (uint32_t)(0x9E3779B9u * (unsigned)(i + 1)));
+    }
+    for (int k = 0; k < 2; ++k) ai_seed_[k].assign((size_t)n_, 0u);
+    for (int i = 0; i < n_; ++i) {
+      ai_seed_[0][(size_t)i] = (uint32_t)game_rng_[(size_t)i]();
+      if (n_ai_ == 2) ai_seed_[1][(size_t)i] = (uint32_t)game_rng_[(size_t)i]();
+    }
     int maxB = 1;
     for (int k = 0; k < 2; ++k) if (mcts_[k]) { elfhip_mcts_destroy(mcts_[k]); mcts_[k] = nullptr; }
     for (int k = 0; k < n_ai_; ++k) {
@@ -580,16 +604,9 @@ class SelfPlayEngine : public elfhip_py::Engine {
                           t.alg_opt.unexplored_q_zero ? 1 : 0, t.alg_opt.root_unexplored_q_zero ? 1 : 0,
                           t.persistent_tree ? 1 : 0, t.pick_method == "most_visited" ? 0 : 1, 0, 0};
       ck(elfhip_mcts_create(game_, n_, &o, device_, &mcts_[k]), "mcts_create");
-      // the reference seeds each game's rng with GameOptions.seed (GameBase.h:43-49); init_ai hands every new
-      // AI the game rng's next draw as MCTSActorParams::seed: first draw -> _ai1, second -> _ai2
-      std::vector<uint32_t> seeds(n_);
-      for (int i = 0; i < n_; ++i) {
-        std::mt19937 g(go_.seed + (unsigned)i);
-        uint32_t v = (uint32_t)g();
-        if (k == 1) v = (uint32_t)g();
-        seeds[i] = v;
-      }
-      ck(elfhip_mcts_seed_rng(mcts_[k], seeds.data()), "mcts_seed_rng");
+      // init_ai hands every new AI the game rng's next draw as MCTSActorParams::seed (ClientGameSelfPlay.cc:59):
+      // first draw -> "actor_black", second -> "actor_white", whatever player_swap does to the pointers afterwards
+      ck(elfhip_mcts_seed_rng(mcts_[k], (spec_[k].label == "actor_black" ? ai_seed_[0] : ai_seed_[1]).data()), "mcts_seed_rng");
       maxB = std::max(maxB, spec_[k].B);
     }
     if (maxB > slotB_) {  // leaf-slot arrays are shared by the AIs (one select/backup batch is in flight at a time)
@@ -759,6 +776,23 @@ class SelfPlayEngine : public elfhip_py::Engine {
     hk(hipMemcpy(d_ply_, h_ply_.data(), (size_t)n_ * 4, hipMemcpyHostToDevice), "copy ply");
     hk(hipMemset(d_move_, 0xFF, (size_t)n_ * 2), "memset");   // -1 = no move (a human who has not answered yet)
     bool any_human = false;
+    // policy.sampleAction(&_rng) (ClientGameSelfPlay.cc:94-111): one std::uniform_real_distribution<> draw of the
+    // game's own rng for every searched move at ply <= policy_distri_cutoff
+    const double* d_canon = nullptr;
+    if (go_.policy_distri_cutoff > 0) {
+      h_canon_.assign((size_t)n_, 0.0);
+      bool any_draw = false;
+      for (int i = 0; i < n_; ++i)
+        if (!h_human_[i] && !h_ponly_[i] && !h_force_end_[i] && pre_ply[i] <= go_.policy_distri_cutoff) {
+          h_canon_[(size_t)i] = std::generate_canonical<double, 53>(game_rng_[(size_t)i]);
+          any_draw = true;
+        }
+      if (any_draw) {
+        if (!d_canon_) dmalloc(&d_canon_, (size_t)n_ * 8);
+        hk(hipMemcpy(d_canon_, h_canon_.data(), (size_t)n_ * 8, hipMemcpyHostToDevice), "copy draws");
+        d_canon = (const double*)d_canon_;
+      }
+    }
     for (int k = 0; k < n_ai_; ++k) {
       std::vector<uint8_t> own(n_), po(n_);
       bool any_po = false;
@@ -770,7 +804,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
       }
       set_active(k, own);
       // chooseAction + mcts_make_diverse_move + getValue (ClientGameSelfPlay.cc:94-122)
-      ck(elfhip_mcts_pick_moves(mcts_[k], (const int32_t*)d_ply_, go_.policy_distri_cutoff, go_.seed, move_counter_,
+      ck(elfhip_mcts_pick_moves(mcts_[k], (const int32_t*)d_ply_, go_.policy_distri_cutoff, d_canon,
                                 (int16_t*)d_move_, (uint8_t*)d_pol_, (float*)d_val_), "mcts_pick_moves");
       if (any_po) {  // actPolicyOnly: strongest prior, no diverse move, no policy record (:349-357)
         hk(hipMemcpy(d_m8_, po.data(), (size_t)n_, hipMemcpyHostToDevice), "copy mask");
@@ -778,7 +812,6 @@ class SelfPlayEngine : public elfhip_py::Engine {
       }
       ck(elfhip_mcts_set_active(mcts_[k], nullptr), "mcts_set_active");
     }
-    ++move_counter_;
     if (any_human) {  // the human's moves replace the (absent) AI moves of those games
       hk(hipMemcpy(h_move_.data(), d_move_, (size_t)n_ * 2, hipMemcpyDeviceToHost), "copy");
       for (int i = 0; i < n_; ++i) if (h_human_[i]) h_move_[i] = h_hmove_[i];
@@ -870,7 +903,10 @@ class SelfPlayEngine : public elfhip_py::Engine {
   Phase phase_ = BEGIN;
   int rollouts_ = 0, chunk_n_ = 0;
   size_t cursor_ = 0;
-  uint64_t move_counter_ = 0;
+  std::vector<std::mt19937> game_rng_;
+  std::vector<uint32_t> ai_seed_[2];
+  std::vector<double> h_canon_;
+  void* d_canon_ = nullptr;
   SharedMem* serving_ = nullptr;
   bool running_ = false, restart_pending_ = false, waiting_ = false, switch_sides_ = false;
   DistriClient client_;

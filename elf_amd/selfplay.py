@@ -6,6 +6,8 @@ mcts_make_diverse_move / addMCTSPolicy (uint8-quantised visit policy) -> mcts_up
 (predicted value) -> GameState::forward -> on terminal: setFinalValue, endGame (tree reset), record,
 restart.  Game records are fixed-stride slabs (DESIGN.md / SURVEY.md 8e) instead of the reference's JSON.
 Everything numeric runs in libelfhip.so; torch only holds buffers and does index bookkeeping."""
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -13,6 +15,38 @@ from . import _lib
 from ._lib import check
 from .boards import BoardBatch
 from .mcts import TreeSearchBatch
+
+
+class GameRng:
+    """n std::mt19937 streams, one per game: the reference's GameBase::_rng (common/GameBase.h:43-49,76).  With
+    GameOptions.seed != 0 every game is seeded with it (as in the reference); seed == 0 is time-based there, here a
+    fixed per-game value.  Host only (elfhip_rng_*)."""
+
+    def __init__(self, n, seed):
+        self.L, self.n = _lib.lib(), int(n)
+        seeds = np.full(self.n, seed, dtype=np.uint32) if seed else ((np.arange(1, self.n + 1, dtype=np.uint64) * 0x9E3779B9) & 0xFFFFFFFF).astype(np.uint32)
+        h = C.c_void_p()
+        check(self.L.elfhip_rng_create(self.n, seeds.ctypes.data, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.elfhip_rng_destroy(self.h)
+            self.h = None
+
+    def next_u32(self, which=None):
+        """`_rng()` of the selected games (params.seed = _rng(), ClientGameSelfPlay.cc:59)"""
+        out = np.zeros(self.n, dtype=np.uint32)
+        w = None if which is None else np.ascontiguousarray(which, dtype=np.uint8)
+        check(self.L.elfhip_rng_next_u32(self.h, None if w is None else w.ctypes.data, out.ctypes.data))
+        return out
+
+    def canonical(self, which=None):
+        """the draw std::uniform_real_distribution<> makes for the selected games (policy.sampleAction(&_rng), :102)"""
+        out = np.zeros(self.n, dtype=np.float64)
+        w = None if which is None else np.ascontiguousarray(which, dtype=np.uint8)
+        check(self.L.elfhip_rng_canonical(self.h, None if w is None else w.ctypes.data, out.ctypes.data))
+        return out
 
 
 class SelfPlayBatch:
@@ -23,7 +57,10 @@ class SelfPlayBatch:
         self.bb = BoardBatch(game, self.n, device)
         self.ts = TreeSearchBatch(game, self.n, device, **ts_kwargs)
         self.net = net
-        self.cutoff, self.seed, self.counter = int(policy_distri_cutoff), int(seed), 0
+        self.cutoff, self.seed = int(policy_distri_cutoff), int(seed)
+        self.rng = GameRng(self.n, self.seed)
+        self.ts.seed_rng(self.rng.next_u32())          # init_ai: MCTSActorParams.seed = _rng()
+        self._canon = torch.zeros(self.n, dtype=torch.float64, device=self.device)
         info = self.bb.info
         self.A, self.max_ply = info.num_actions, info.max_ply
         dev = self.device
@@ -50,10 +87,15 @@ class SelfPlayBatch:
         if not bool(ok.all()):   # TreeSearchT::setRootNodeState: "Root state is not the same" (tree_search.h:582)
             raise _lib.ElfHipError("tree search: the stored root of %d tree(s) differs from the game state" % int((ok == 0).sum().item()))
         ts.search_with_recovery(bb, ts.run_uniform if self.net is None else (lambda: ts.run(self._evaluate)))
-        check(ts.L.elfhip_mcts_pick_moves(ts.h, self.ply.data_ptr(), self.cutoff, self.seed, self.counter,
+        canon = None
+        if self.cutoff > 0:                            # mcts_make_diverse_move: games at ply <= cutoff sample their move
+            which = (self.ply <= self.cutoff).cpu().numpy().astype(np.uint8)
+            if which.any():
+                self._canon.copy_(torch.from_numpy(self.rng.canonical(which)))
+                canon = self._canon
+        check(ts.L.elfhip_mcts_pick_moves(ts.h, self.ply.data_ptr(), self.cutoff, canon.data_ptr() if canon is not None else None,
                                           self._move.data_ptr(), self._pol.data_ptr() if self._pol is not None else None,
                                           self._val.data_ptr()))
-        self.counter += 1
         idx = torch.arange(self.n, device=self.device)
         self.moves[idx, self.nmoves] = self._move
         self.values[idx, self.nmoves] = self._val

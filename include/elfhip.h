@@ -51,7 +51,7 @@ const char* elfhip_last_error(void);
 /* Library / device sanity: returns number of visible HIP devices (>=0) or a negative error. */
 int elfhip_device_count(void);
 /* Version of this ABI (bumped on incompatible change). */
-int elfhip_abi_version(void);
+int elfhip_abi_version(void);   /* 2: elfhip_mcts_pick_moves takes the sampling draws instead of a seed */
 
 /* Static per-game geometry (no GPU needed). */
 typedef struct {
@@ -195,14 +195,31 @@ int elfhip_mcts_result(elfhip_mcts* m, int16_t* d_best, int32_t* d_total_visits,
  *   d_policy_u8 (nullable) u8 [n][num_actions] = GameStateExt::addMCTSPolicy quantisation
  *     uchar(p / max_p * 255)  (GameStateExt.h:79-100);
  *   d_value (nullable) f32 [n] = MCTSGameAI::getValue (best edge Q, or root V when unvisited);
- *   d_move i16 [n] = chooseAction's best action, or, where d_ply[i] <= policy_distri_cutoff, an action
- *     sampled in proportion to visit counts (mcts_make_diverse_move).  The reference samples with
- *     std::mt19937 + std::uniform_real_distribution; here r = splitmix64(seed + tree*GOLDEN + counter)
- *     mod total_visits over the cumulative counts in edge order - same distribution, different
- *     stream, so sampled games are not bit-comparable (parity configs use cutoff 0).
- * d_ply (nullable = never sample): i32 [n] current ply of each game (starts at 1 like getPly()). */
-int elfhip_mcts_pick_moves(elfhip_mcts* m, const int32_t* d_ply, int policy_distri_cutoff, uint64_t seed,
-                           uint64_t counter, int16_t* d_move, uint8_t* d_policy_u8, float* d_value);
+ *   d_move i16 [n] = chooseAction's best action, or, where d_ply[i] <= policy_distri_cutoff, the action
+ *     MCTSPolicy::sampleAction draws (tree_search_base.h:263-269 -> elf_utils::sample_multinomial,
+ *     elf/utils/utils.h:162-185): Z = float sum of the normalised policy in edge order,
+ *     float rd = std::uniform_real_distribution<>(0, Z)(game rng), first edge whose running float sum exceeds rd
+ *     (the last edge when none does).  The distribution's draw is d_canonical[i] * Z: d_canonical f64 [n] holds
+ *     the game rng's std::generate_canonical<double, 53> value for each game that samples (elfhip_rng_canonical
+ *     below makes them from per-game std::mt19937s, the reference's GameBase::_rng) - bit-identical moves.
+ * d_ply (nullable = never sample): i32 [n] current ply of each game (starts at 1 like getPly());
+ * d_canonical (nullable = never sample). */
+int elfhip_mcts_pick_moves(elfhip_mcts* m, const int32_t* d_ply, int policy_distri_cutoff, const double* d_canonical,
+                           int16_t* d_move, uint8_t* d_policy_u8, float* d_value);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-game random streams: n std::mt19937, the reference's GameBase::_rng (common/GameBase.h:43-49,76), host only.
+ * What the self-play loop draws from it: MCTSActorParams::seed = _rng() for every AI that init_ai builds
+ * (ClientGameSelfPlay.cc:59; elfhip_rng_next_u32 -> elfhip_mcts_seed_rng) and one
+ * std::uniform_real_distribution<> draw per sampled move (:102; elfhip_rng_canonical -> elfhip_mcts_pick_moves).
+ * h_which u8 [n] (nullable = all) selects the streams that draw; the others' outputs are left untouched.
+ * The generators are the host libstdc++'s, as in the reference.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct elfhip_rng elfhip_rng;
+int elfhip_rng_create(int n, const uint32_t* h_seeds, elfhip_rng** out);
+int elfhip_rng_destroy(elfhip_rng* r);
+int elfhip_rng_next_u32(elfhip_rng* r, const uint8_t* h_which, uint32_t* h_out);
+int elfhip_rng_canonical(elfhip_rng* r, const uint8_t* h_which, double* h_out);
 /* Two AIs per game (ClientGameSelfPlay::restart, common/ClientGameSelfPlay.cc:155-196: _ai1 "actor_black", _ai2
  * "actor_white" with its own c_puct / rollouts; :344-346 curr_ai = white to move && _ai2 ? _ai2 : _ai1): one
  * elfhip_mcts handle per AI over the same games, and per move each handle searches only the games whose side
@@ -296,6 +313,15 @@ int elfhip_scatter_rows(const void* d_src, long long row_bytes, const int32_t* d
  * ---------------------------------------------------------------------------------------------- */
 int elfhip_test_sort_order(int n, const float* h_keys, uint16_t* h_order);
 int elfhip_test_umap_order(int m, const uint16_t* h_keys, uint16_t* h_iter_keys);
+/* One NodeT::findMove (tree_search_node.h:218-244 -> UCT :385-421 -> EdgeInfo::getScore tree_search_base.h:175-201)
+ * by the search kernels' own descent code on a hand-built node (needs a GPU): n_edges <= 512 edges in edge order with
+ * their prior / reward / num_visits / virtual_loss, the node's flipQSign_, unsignedMeanQ_, unsignedParentQ_ and
+ * numVisits_ (node_depth 0); of `opt` only use_prior, c_puct, unexplored_q_zero and root_unexplored_q_zero are read.
+ * Outputs: index of the chosen edge and the node's new unsignedMeanQ_.  Exists so that tests can hold the kernels to
+ * known answers derived from the reference's source by hand (tests/golden/uct_known_answers.json). */
+int elfhip_test_find_move(int n_edges, const float* h_prior, const float* h_reward, const int32_t* h_visits, const float* h_vloss,
+                          int flip, float mean_q, float parent_q, int num_visits, const elfhip_ts_options* opt, int device,
+                          int* h_best_edge, float* h_new_mean_q);
 /* the same order computed on `device` by the wave-parallel form the search kernels use (needs a GPU) */
 int elfhip_test_umap_order_wave(int m, const uint16_t* h_keys, uint16_t* h_iter_keys, int device);
 

@@ -387,6 +387,51 @@ int ogomcts_run(void* h, const go_state* g, int max_edges, int* n_edges, uint16_
   return run<GoTraits>((GoMcts*)h, g, max_edges, n_edges, actions, visits, rewards, priors, total_visits, root_value, best_q);
 }
 
+// The game's own rng and its uses in the self-play loop, with the library types the reference uses:
+// GameBase::_rng (common/GameBase.h:43-49,76), params.seed = _rng() (ClientGameSelfPlay.cc:59) and
+// mcts_make_diverse_move (:94-111) = MCTSGameAI::getMCTSPolicy (mcts/MCTSGameAI.h:48-54: visit counts, normalize())
+// + MCTSPolicy::sampleAction (tree_search_base.h:251-269) + elf_utils::sample_multinomial (elf/utils/utils.h:162-185).
+void* orng_create(unsigned seed) { return new std::mt19937(seed); }
+void orng_destroy(void* h) { delete (std::mt19937*)h; }
+unsigned orng_next_u32(void* h) { return (unsigned)(*(std::mt19937*)h)(); }
+// visits in edge (iteration) order -> index of the sampled edge
+int orng_sample_policy(void* h, int n, const int* visits) {
+  std::vector<std::pair<Action, float>> policy;
+  for (int i = 0; i < n; ++i) policy.push_back(std::make_pair((Action)i, (float)visits[i]));   // MCTSResultT::addActions: score = num_visits
+  float exp_sum = 0;                                                                           // normalize(t = 1)
+  for (auto& e : policy) { float x = std::pow(e.second, 1.0 / 1); e.second = x; exp_sum += x; }
+  for (auto& e : policy) e.second /= exp_sum;
+  std::vector<float> accu(policy.size() + 1);                                                  // sample_multinomial
+  float Z = 0.0;
+  for (const auto& vv : policy) Z += vv.second;
+  std::uniform_real_distribution<> dis(0, Z);
+  float rd = dis(*(std::mt19937*)h);
+  accu[0] = 0;
+  for (size_t i = 1; i < accu.size(); i++) {
+    accu[i] = policy[i - 1].second + accu[i - 1];
+    if (rd < accu[i]) return (int)(i - 1);
+  }
+  return (int)policy.size() - 1;
+}
+
+// One findMove on a hand-built node (tests/golden/uct_known_answers.json): edges are inserted with the given keys
+// in the given order; returns the chosen action and the node's new unsignedMeanQ_.
+void omcts_test_find_move(int n, const uint16_t* keys, const float* prior, const float* reward, const int* visits,
+                          const float* vloss, int flip, float mean_q, float parent_q, int num_visits, int depth,
+                          const int* iopt4, float c_puct, int* best_action, float* new_mean_q) {
+  AmMcts m;
+  m.opt = TsOptions{1, 1, 0, iopt4[0], c_puct, iopt4[1], iopt4[2], 1, 0};
+  NodeT<am_game> node(parent_q);
+  node.status = 2; node.flip = flip != 0; node.meanQ = mean_q; node.parentQ = parent_q; node.numVisits = num_visits;
+  for (int i = 0; i < n; ++i) {
+    Edge e(prior[i]); e.reward = reward[i]; e.num_visits = visits[i]; e.virtual_loss = vloss[i];
+    node.edges.insert(std::make_pair((Action)keys[i], e));
+  }
+  Action a = 0;
+  m.find_move(&node, depth, &a);
+  *best_action = a; *new_mean_q = node.meanQ;
+}
+
 int omcts_run(void* h, const am_game* g, int max_edges, int* n_edges, uint16_t* actions, int* visits,
               float* rewards, float* priors, int* total_visits, float* root_value, float* best_q) {
   return run<AmTraits>((AmMcts*)h, g, max_edges, n_edges, actions, visits, rewards, priors, total_visits, root_value, best_q);

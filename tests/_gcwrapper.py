@@ -19,6 +19,7 @@ class Wrapper:
         """device_keys: keys whose arrays are torch CUDA tensors bound by device pointer (no reference counterpart: the
         reference's batches are pinned host tensors; here a GPU-side actor can read / write them in place)."""
         self.GC, self.ctx = GC, GC.ctx()
+        self.stamp_rv = True    # reply "rv" = the version of the actor's model, as Evaluator.actor does (trainer.py:146-147)
         self.batches, self.name2idx, self.idx2name, self.cb = {}, {}, {}, {}
         for name, v in desc.items():
             keys_in, keys_rep = list(v.get("input") or []), list(v.get("reply") or [])
@@ -59,6 +60,11 @@ class Wrapper:
         reply = self.cb[idx](picked, bs) if idx in self.cb else None
         if isinstance(reply, dict):
             assert set(reply) == set(self.batches[idx]["reply"])
+            if self.stamp_rv and "rv" in reply and hasattr(self.GC, "aiInfo"):
+                base = self.idx2name[idx].replace("checkers_", "")
+                ver = [a["version"] for a in self.GC.aiInfo() if a["actor"] == base]
+                if ver and ver[0] >= 0:
+                    reply = dict(reply, rv=np.full(bs, ver[0], dtype=np.int64))
             for k, v in reply.items():
                 dst = self.batches[idx]["reply"][k]
                 if isinstance(dst, np.ndarray):

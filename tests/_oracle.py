@@ -145,6 +145,14 @@ def oracle():
             getattr(L, pre + "run").argtypes = [C.c_void_p, C.c_void_p, C.c_int, _i32p, _u16p, _i32p, _f32p, _f32p, _i32p, _f32p, _f32p]
             getattr(L, pre + "run").restype = C.c_int
             getattr(L, pre + "scripted_policy").argtypes = [_u64p, C.c_uint64, _f32p, _f32p]
+        L.omcts_test_find_move.argtypes = [C.c_int, _u16p, _f32p, _f32p, _i32p, _f32p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                           _i32p, C.c_float, _i32p, _f32p]
+        L.orng_create.argtypes = [C.c_uint]
+        L.orng_create.restype = C.c_void_p
+        L.orng_destroy.argtypes = [C.c_void_p]
+        L.orng_next_u32.argtypes = [C.c_void_p]
+        L.orng_next_u32.restype = C.c_uint
+        L.orng_sample_policy.argtypes = [C.c_void_p, C.c_int, _i32p]
         L.omcts_std_sort_desc.argtypes = [C.c_int, _f32p, _u16p]
         L.omcts_std_umap_order.argtypes = [C.c_int, _u16p, _u16p]
         _oracle = L

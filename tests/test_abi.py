@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_built_and_loads():
     assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
     L = _lib.lib()
-    assert L.elfhip_abi_version() == 1
+    assert L.elfhip_abi_version() == 2
 
 
 def test_every_declared_symbol_is_exported():

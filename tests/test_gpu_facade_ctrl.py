@@ -268,3 +268,19 @@ def test_go_game_context_through_the_same_facade():
         om.advance(r["best"])
     assert [int(x) for x in g.export(0)] == GC.getGame(0).getStateWords() == GC.getGame(1).getStateWords()
     w.stop()
+
+
+def test_reply_of_another_model_version_is_refused():
+    """MCTSGameActor::post_nn_result (mcts/MCTSGameActor.h:222-229): an AI built for model version v throws when a
+    reply carries another version; an async request (required_version = -1) accepts any."""
+    GC, w = _ctx(2, 8)
+    GC.getClient().setRequest(3, -1, 1)
+    w.reg_callback("actor_black", _uniform)
+    w.start()
+    for _ in range(6):
+        w.run()                                  # replies stamped with version 3: accepted
+    w.stamp_rv = False                           # now the actor answers with rv = 0
+    with pytest.raises(RuntimeError, match="model version 0 and required version 3 are not consistent"):
+        for _ in range(50):
+            w.run()
+    w.stop()

@@ -91,7 +91,7 @@ def test_go_selfplay_driver_runs_with_network():
     n = 32
     net = PolicyValueNet(max_batch=n * 8, **cfg)
     net.load_state_dict(seeded_model(seed=1, **cfg).state_dict())
-    sp = SelfPlayBatch(GO19, n, net=net, policy_distri_cutoff=30, seed=3, num_rollouts_per_thread=32,
+    sp = SelfPlayBatch(GO19, n, net=net, policy_distri_cutoff=30, seed=0, num_rollouts_per_thread=32,
                        num_rollouts_per_batch=8, virtual_loss=1, c_puct=1.5, max_nodes=192, max_edges=60000)
     for step in range(6):
         sp.step()

@@ -82,7 +82,7 @@ def test_two_ais_with_overrides_match_oracle(policy_kind):
                 ts[k].run_uniform()
             else:
                 ts[k].run(ev[k])
-            ts[k].L.elfhip_mcts_pick_moves(ts[k].h, None, 0, 0, 0, move.data_ptr(), None, val.data_ptr())
+            ts[k].L.elfhip_mcts_pick_moves(ts[k].h, None, 0, None, move.data_ptr(), None, val.data_ptr())
         got_m, got_v = move.cpu().numpy(), val.cpu().numpy()
         want = np.full(n, -1, dtype=np.int16)
         for i, g in enumerate(games):
@@ -135,7 +135,7 @@ def test_policy_only_for_black_matches_oracle():
         # full search for white
         ts.set_active(torch.tensor(((pl == 1) & alive).astype(np.uint8), device="cuda"))
         ts.run(ev)
-        ts.L.elfhip_mcts_pick_moves(ts.h, None, 0, 0, 0, move.data_ptr(), None, val.data_ptr())
+        ts.L.elfhip_mcts_pick_moves(ts.h, None, 0, None, move.data_ptr(), None, val.data_ptr())
         # policy only for black: one batch where the root is unvisited, then strongest prior
         ts.set_active(torch.tensor((pol_only & ~visited).astype(np.uint8), device="cuda"))
         st, ft, ne = ts.select(want_states=True, want_features=True)
@@ -185,7 +185,7 @@ def _two_ai_generic(game_id, n, nmoves, make_games, side_of, run_oracle, forward
             ts[k].set_active(torch.tensor(((pl == k) & ~term).astype(np.uint8), device="cuda"))
             assert ts[k].set_roots(bb).cpu().numpy().all()
             ts[k].run_uniform()
-            ts[k].L.elfhip_mcts_pick_moves(ts[k].h, None, 0, 0, 0, move.data_ptr(), None, None)
+            ts[k].L.elfhip_mcts_pick_moves(ts[k].h, None, 0, None, move.data_ptr(), None, None)
         got = move.cpu().numpy()
         for i in range(n):
             if term[i]:
