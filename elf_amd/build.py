@@ -97,7 +97,7 @@ def build_pybind(force=False, verbose=False):
     inc = ["-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], "-I/opt/rocm/include"]
     base = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__", "-Wall"] + inc
     link = ["-L" + HERE, "-lelfhip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
-    hdrs = [os.path.join(PYB, "facade.h"), os.path.join(PYB, "board_view.h"), os.path.join(HERE, "..", "include", "elfhip.h")]
+    hdrs = [os.path.join(PYB, "facade.h"), os.path.join(PYB, "board_view.h"), os.path.join(PYB, "options_logging.h"), os.path.join(HERE, "..", "include", "elfhip.h")]
     jobs = [("_elf", os.path.join(PYB, "elf_module.cc"), [], [])]
     for name, gid in GAME_MODULES.items():
         jobs.append((name, os.path.join(PYB, "game_module.cc"), ["-DELFGAME_MODULE=" + name, "-DELFGAME_ID=%d" % gid], link))

@@ -5,6 +5,7 @@
 #include <pybind11/stl.h>
 
 #include "facade.h"
+#include "options_logging.h"
 
 namespace py = pybind11;
 using namespace elfhip_py;
@@ -74,8 +75,9 @@ PYBIND11_MODULE(_elf, m) {
       .def_readwrite("root_epsilon", &TSOptions::root_epsilon)
       .def_readwrite("root_alpha", &TSOptions::root_alpha);
 
-  // the reference also has _logging / _options submodules (option-spec plumbing, out of scope:
-  // SURVEY.md section 2); empty submodules keep `from _elf import *` + attribute probes working
-  m.def_submodule("_logging");
-  m.def_submodule("_options");
+  // src_cpp/elf/Pybind.cc:108-112: the submodules the reference's Python package subclasses and star-imports
+  auto m_logging = m.def_submodule("_logging");
+  register_logging(m_logging);
+  auto m_options = m.def_submodule("_options");
+  register_options(m_options);
 }

@@ -134,7 +134,7 @@ class Context {  // elf::Context (elf/base/context.h:223-420)
   SharedMem* wait(int timeout_usec);
   void step(ReplyStatus success);
   void stop();
-  std::string version() const { return "elfhip-mi355x-abi1"; }
+  std::string version() const { return "elfhip-mi355x-abi2"; }
   bool started() const { return started_; }
 
  private:
