@@ -49,91 +49,134 @@ def cpu_baseline(threads=16, boards_per_thread=256, plies=8192):
                       % (threads, boards_per_thread, plies, dt)}
 
 
-def nn_rollouts_leg(games, moves, local, world, barrier):
+class NNLeg:
     """Second half of BASELINE.json's metric: NN-evaluated MCTS rollouts/s on configs[3] (Go 19x19 self-play,
     4,096 games per GPU, 1,600 rollouts/move, 8 leaves per batch, virtual loss 1, 20-block x 224 ResNet in bf16
     MFMA, seeded random weights), measured over WHOLE moves: set roots, 200 search batches (select: descents + Go
     moves + 18 planes -> the rows that need the network are gathered into a dense batch -> forward -> replies
     scattered back -> backup), pick the most visited move, play it, treeAdvance.  Only leaves that went through the
-    network count; duplicate leaves of a batch and terminal leaves cost no network time."""
-    import numpy as np
-    import torch
-    from elf_amd._lib import check
-    from elf_amd.boards import BoardBatch, GO19
-    from elf_amd.mcts import TreeSearchBatch
-    from elf_amd.net import PolicyValueNet, random_state_dict
-    n, B, R, blocks, dim = games, 8, 1600, 20, 224
-    bb = BoardBatch(GO19, n, device=local)
-    bb.playout(40, seed=SEED)                    # synthetic openings: 40 random-legal plies
-    bb.import_states(bb.export_states())         # clean game record for the planes / superko set
-    max_nodes = R + R // 2 + 64
-    ts = TreeSearchBatch(GO19, n, device=local, num_rollouts_per_thread=R, num_rollouts_per_batch=B, virtual_loss=1, c_puct=1.5,
-                         max_nodes=max_nodes, max_edges=max_nodes * 300)
-    cfg = dict(planes=18, board=19, dim=dim, num_block=blocks, num_action=362)
-    net = PolicyValueNet(max_batch=n * B, device=local, **cfg)
-    net.load_state_dict(random_state_dict(seed=0, **cfg))
-    S = n * B
-    feat = torch.empty((S, 18, 19, 19), dtype=torch.float32, device="cuda")
-    cfeat = torch.empty_like(feat)
-    need = torch.empty((n, B), dtype=torch.uint8, device="cuda")
-    pi = torch.zeros((S, 362), dtype=torch.float32, device="cuda")
-    v = torch.zeros((S, 1), dtype=torch.float32, device="cuda")
-    cpi = torch.empty_like(pi)
-    cv = torch.empty_like(v)
-    L = ts.L
-    nbatch = (R + B - 1) // B
-    fwd_ev = []
-    rows = [0]
+    network count; duplicate leaves of a batch and terminal leaves cost no network time.
+    With several ranks the path's two collectives run as they would in production (outside the timed moves): the
+    weights come from rank 0 by broadcast + device-side load, the moves played go back to rank 0 by a record gather.
+    The phases are separate methods so that the caller can agree on success across ranks between them."""
 
-    def search_batch(timed):
-        check(L.elfhip_mcts_select(ts.h, None, feat.data_ptr(), need.data_ptr()))
-        idx = torch.nonzero(need.view(-1)).to(torch.int32).view(-1)     # rows that need the network (index plumbing only)
+    def __init__(self, games, local, rank, world, max_nodes=0):
+        import torch
+        from elf_amd.boards import BoardBatch, GO19
+        from elf_amd.mcts import TreeSearchBatch
+        from elf_amd.net import PolicyValueNet
+        self.torch = torch
+        self.local, self.rank, self.world = local, rank, world
+        n, B, R, blocks, dim = games, 8, 1600, 20, 224
+        self.shape = (n, R, B, blocks, dim)
+        self.bb = bb = BoardBatch(GO19, n, device=local)
+        bb.playout(40, seed=SEED, first_board_id=rank * n)   # synthetic openings: 40 random-legal plies, other games on every rank
+        bb.import_states(bb.export_states())                 # clean game record for the planes / superko set
+        max_nodes = max_nodes or R + R // 2 + 64
+        self.ts = TreeSearchBatch(GO19, n, device=local, num_rollouts_per_thread=R, num_rollouts_per_batch=B, virtual_loss=1, c_puct=1.5,
+                                  max_nodes=max_nodes, max_edges=max_nodes * 300)
+        self.cfg = dict(planes=18, board=19, dim=dim, num_block=blocks, num_action=362)
+        self.chunk = min(n * B, 32768)                       # rows per network call (activation buffers are sized for this)
+        self.net = PolicyValueNet(max_batch=self.chunk, device=local, **self.cfg)
+        S = n * B
+        self.feat = torch.empty((S, 18, 19, 19), dtype=torch.float32, device="cuda")
+        self.cfeat = torch.empty_like(self.feat)
+        self.need = torch.empty((n, B), dtype=torch.uint8, device="cuda")
+        self.pi = torch.zeros((S, 362), dtype=torch.float32, device="cuda")
+        self.v = torch.zeros((S, 1), dtype=torch.float32, device="cuda")
+        self.cpi = torch.empty_like(self.pi)
+        self.cv = torch.empty_like(self.v)
+        self.nbatch = (R + B - 1) // B
+        self.fwd_ev, self.rows, self.played = [], 0, []
+
+    def load_weights(self):
+        """rank 0 holds the model (version 1); everybody else receives it.  Returns the milliseconds the update took."""
+        import numpy as np
+        from elf_amd import dist as edist
+        from elf_amd.net import pack_state_dict, random_state_dict
+        torch = self.torch
+        flat = torch.zeros(self.net.param_count(), dtype=torch.float32, device="cuda")
+        if self.rank == 0:
+            flat.copy_(torch.from_numpy(pack_state_dict(random_state_dict(seed=0, **self.cfg), self.cfg["num_block"])))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if self.world > 1:
+            edist.update_model(self.net, flat, 1, src=0)
+        else:
+            self.net.load_device(flat, 1)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+
+    def search_batch(self, timed):
+        from elf_amd._lib import check
+        torch, ts, L = self.torch, self.ts, self.ts.L
+        check(L.elfhip_mcts_select(ts.h, None, self.feat.data_ptr(), self.need.data_ptr()))
+        idx = torch.nonzero(self.need.view(-1)).to(torch.int32).view(-1)     # rows that need the network (index plumbing only)
         k = int(idx.numel())
         if k:
-            check(L.elfhip_gather_rows(feat.data_ptr(), 18 * 361 * 4, idx.data_ptr(), k, cfeat.data_ptr(), local, None))
+            check(L.elfhip_gather_rows(self.feat.data_ptr(), 18 * 361 * 4, idx.data_ptr(), k, self.cfeat.data_ptr(), self.local, None))
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            check(L.elfhip_net_forward(net.h, cfeat.data_ptr(), k, cpi.data_ptr(), None, cv.data_ptr()))
+            for c0 in range(0, k, self.chunk):
+                kc = min(self.chunk, k - c0)
+                check(L.elfhip_net_forward(self.net.h, self.cfeat[c0:].data_ptr(), kc, self.cpi[c0:].data_ptr(), None, self.cv[c0:].data_ptr()))
             if timed:
                 e1.record()
-                fwd_ev.append((e0, e1))
-                rows[0] += k
-            check(L.elfhip_scatter_rows(cpi.data_ptr(), 362 * 4, idx.data_ptr(), k, pi.data_ptr(), local, None))
-            check(L.elfhip_scatter_rows(cv.data_ptr(), 4, idx.data_ptr(), k, v.data_ptr(), local, None))
-        check(L.elfhip_mcts_backup(ts.h, pi.data_ptr(), v.data_ptr()))
+                self.fwd_ev.append((e0, e1))
+                self.rows += k
+            check(L.elfhip_scatter_rows(self.cpi.data_ptr(), 362 * 4, idx.data_ptr(), k, self.pi.data_ptr(), self.local, None))
+            check(L.elfhip_scatter_rows(self.cv.data_ptr(), 4, idx.data_ptr(), k, self.v.data_ptr(), self.local, None))
+        check(L.elfhip_mcts_backup(ts.h, self.pi.data_ptr(), self.v.data_ptr()))
 
-    def one_move(timed):
+    def one_move(self, timed, nbatch=None):
+        ts, bb = self.ts, self.bb
         assert ts.set_roots(bb).cpu().numpy().all()
-        for _ in range(nbatch):
-            search_batch(timed)
+        for _ in range(nbatch or self.nbatch):
+            self.search_batch(timed)
         best = ts.result()["best"]
         bb.forward(best)
         ts.treeAdvance(best)
+        self.played.append(best)
 
-    for _ in range(2):                           # warm-up: two search batches, then fresh trees again
-        assert ts.set_roots(bb).cpu().numpy().all()
-        search_batch(False)
-    ts.clear()
-    barrier()
-    s0, _ = ts.stats()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(moves):
-        one_move(True)
-    barrier()
-    dt = time.perf_counter() - t0
-    s1, flags = ts.stats()
-    evals = s1["evals"] - s0["evals"]
-    rollouts = s1["rollouts"] - s0["rollouts"]
-    depth = (s1["depth_sum"] - s0["depth_sum"]) / max(1, rollouts)
-    fwd_ms = sum(a.elapsed_time(b) for a, b in fwd_ev)
-    macs = 361 * (9 * 18 * dim + blocks * 2 * 9 * dim * dim + 2 * dim) + 361 * 362 + 361 * 256 + 256   # SURVEY.md 8(d)
-    tf = 2.0 * macs * rows[0] / (fwd_ms * 1e-3) / 1e12
-    return {"evals": evals, "rollouts": rollouts, "dt": dt, "mean_depth": depth, "fwd_ms": fwd_ms, "rows": rows[0], "tf": tf,
-            "parked": int((flags != 0).sum().item()), "macs": macs, "moves": moves, "nbatch": nbatch,
-            "bytes_per_tree": ts.bytes_per_tree() if hasattr(ts, "bytes_per_tree") else None,
-            "cfg": (n, R, B, blocks, dim)}
+    def run(self, moves, sync, nbatch=None):
+        torch, ts = self.torch, self.ts
+        for _ in range(2):                           # warm-up: two search batches, then fresh trees again
+            assert ts.set_roots(self.bb).cpu().numpy().all()
+            self.search_batch(False)
+        ts.clear()
+        self.played = []
+        sync()
+        s0, _ = ts.stats()
+        t0 = time.perf_counter()
+        for _ in range(moves):
+            self.one_move(True, nbatch)
+        sync()
+        dt = time.perf_counter() - t0
+        s1, flags = ts.stats()
+        n, R, B, blocks, dim = self.shape
+        rollouts = s1["rollouts"] - s0["rollouts"]
+        fwd_ms = sum(a.elapsed_time(b) for a, b in self.fwd_ev)
+        macs = 361 * (9 * 18 * dim + blocks * 2 * 9 * dim * dim + 2 * dim) + 361 * 362 + 361 * 256 + 256   # SURVEY.md 8(d)
+        free, total = torch.cuda.mem_get_info()
+        return {"evals": s1["evals"] - s0["evals"], "rollouts": rollouts, "dt": dt,
+                "mean_depth": (s1["depth_sum"] - s0["depth_sum"]) / max(1, rollouts), "fwd_ms": fwd_ms, "rows": self.rows,
+                "tf": 2.0 * macs * self.rows / max(1e-9, fwd_ms * 1e-3) / 1e12, "parked": int((flags & 15).ne(0).sum().item()), "macs": macs,
+                "moves": moves, "nbatch": nbatch or self.nbatch, "bytes_per_tree": ts.bytes_per_tree(), "arenas": ts.arenas(),
+                "hbm_used_gb": (total - free) / 1e9, "cfg": self.shape}
+
+    def gather_moves(self):
+        """the moves of the timed span as a record slab -> rank 0.  Returns (ms, number of rows rank 0 holds)."""
+        from elf_amd import dist as edist
+        torch = self.torch
+        n = self.shape[0]
+        slab = dict(game_id=torch.arange(n, dtype=torch.int32, device="cuda") + self.rank * n,
+                    moves=torch.stack(self.played, dim=1).contiguous())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = edist.gather_records(slab, dst=0) if self.world > 1 else slab
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3, (int(got["game_id"].numel()) if got is not None else 0)
 
 
 def nn_rollouts_line(r, evals_all, dt_all, world):
@@ -146,7 +189,7 @@ def nn_rollouts_line(r, evals_all, dt_all, world):
                                    "play + treeAdvance" % (n, R, B, blocks, dim, r["nbatch"])},
             "rollouts_per_step": r["rollouts"] // r["moves"], "evaluated_fraction": r["evals"] / max(1, r["rollouts"]),
             "mean_depth": r["mean_depth"], "network_share_of_time": r["fwd_ms"] * 1e-3 / r["dt"],
-            "parked_trees": r["parked"], "tree_bytes": r["bytes_per_tree"],
+            "parked_trees": r["parked"], "tree_bytes": r["bytes_per_tree"], "tree_arenas": r["arenas"], "hbm_used_gb": r["hbm_used_gb"],
             "roofline": {"bound": "mfma", "achieved": r["tf"], "peak": 2500.0, "unit": "TFLOP/s", "frac": r["tf"] / 2500.0, "traffic": None,
                          "kernel": "conv3x3_board_kernel<224,19,1,*> (41 launches per forward)", "kernel_ms": r["fwd_ms"] / max(1, r["moves"] * r["nbatch"]),
                          "gflop_per_position": 2.0 * r["macs"] / 1e9, "positions_per_sec": r["rows"] / (r["fwd_ms"] * 1e-3)}}
@@ -163,6 +206,8 @@ def main():
     ap.add_argument("--no-nn-rollouts", action="store_true", help="skip the configs[3] leg (NN-evaluated MCTS rollouts/s)")
     ap.add_argument("--nn-games", type=int, default=4096)
     ap.add_argument("--nn-moves", type=int, default=1, help="whole 1,600-rollout moves timed by the configs[3] leg")
+    ap.add_argument("--nn-max-nodes", type=int, default=0, help="tree arena size in nodes (0 = 1,600 + 800 + 64)")
+    ap.add_argument("--nn-batches", type=int, default=0, help="search batches per move (0 = all 200; fewer = a partial move, for sizing runs only)")
     args = ap.parse_args()
 
     import torch
@@ -225,24 +270,41 @@ def main():
     nn = None
     nn_failed = False
     if not args.no_nn_rollouts:
-        # A rank that fails must not leave the others waiting inside a collective: the leg itself runs no
-        # collective; every rank then takes part in the same reductions whatever happened to it.
-        r, err = None, None
+        # A rank that fails must not leave the others waiting inside a collective: after every phase all ranks agree
+        # (one all_reduce they all reach, whatever happened to them) whether to go on.
+        state = {"err": None}
+
+        def phase(fn):
+            out = None
+            if state["err"] is None:
+                try:
+                    out = fn()
+                except Exception as e:
+                    state["err"] = "%s: %s" % (type(e).__name__, e)
+            ok = torch.tensor([0.0 if state["err"] else 1.0], dtype=torch.float64, device="cuda")
+            if world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() == 0 and state["err"] is None:
+                state["err"] = "failed on another rank"
+            return out
+
         barrier()
-        try:
-            r = nn_rollouts_leg(args.nn_games, args.nn_moves, local, world, barrier if world == 1 else torch.cuda.synchronize)
-        except Exception as e:
-            err = "%s: %s" % (type(e).__name__, e)
-        red = torch.tensor([1.0 if r else 0.0, r["dt"] if r else 0.0, float(r["evals"]) if r else 0.0], dtype=torch.float64, device="cuda")
-        ok, tmx, tot_e = red[0:1].clone(), red[1:2].clone(), red[2:3].clone()
-        if world > 1:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
-            dist.all_reduce(tot_e, op=dist.ReduceOp.SUM)
-        if ok.item() > 0:
+        leg = phase(lambda: NNLeg(args.nn_games, local, rank, world, args.nn_max_nodes))
+        bcast_ms = phase(lambda: leg.load_weights())
+        r = phase(lambda: leg.run(args.nn_moves, barrier, args.nn_batches or None))
+        gath = phase(lambda: leg.gather_moves())
+        if state["err"] is None:
+            red = torch.tensor([r["dt"], float(r["evals"])], dtype=torch.float64, device="cuda")
+            tmx, tot_e = red[0:1].clone(), red[1:2].clone()
+            if world > 1:
+                dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+                dist.all_reduce(tot_e, op=dist.ReduceOp.SUM)
             nn = nn_rollouts_line(r, float(tot_e.item()), float(tmx.item()), world)
+            nn["collectives"] = {"weight_update_ms": bcast_ms, "weight_bytes": 4 * leg.net.param_count(),
+                                 "record_gather_ms": gath[0], "record_rows_on_rank0": gath[1],
+                                 "backend": (dist.get_backend() if world > 1 else "none (one rank: device-side load only)")}
         else:   # the headline line is still printed, the process then exits non-zero
-            nn = {"metric": "go_nn_evaluated_mcts_rollouts_per_sec", "value": None, "error": err or "failed on another rank"}
+            nn = {"metric": "go_nn_evaluated_mcts_rollouts_per_sec", "value": None, "error": state["err"]}
             nn_failed = True
     if rank == 0:
         moves_per_launch = moves / max(1, args.steps)

@@ -24,7 +24,7 @@ SYMBOLS = [
     "elfhip_mcts_run_uniform", "elfhip_mcts_select", "elfhip_mcts_backup", "elfhip_mcts_result", "elfhip_mcts_advance",
     "elfhip_mcts_stats", "elfhip_mcts_tree_bytes", "elfhip_mcts_pick_moves", "elfhip_mcts_seed_rng", "elfhip_mcts_root_noise",
     "elfhip_mcts_set_active", "elfhip_mcts_pick_policy_only",
-    "elfhip_net_create", "elfhip_net_destroy", "elfhip_net_set_stream", "elfhip_net_param_count", "elfhip_net_load",
+    "elfhip_net_create", "elfhip_net_destroy", "elfhip_net_set_stream", "elfhip_net_param_count", "elfhip_net_load", "elfhip_net_load_device", "elfhip_net_version",
     "elfhip_net_forward", "elfhip_net_set_precision",
     "elfhip_rng_create", "elfhip_rng_destroy", "elfhip_rng_next_u32", "elfhip_rng_canonical",
 ]
@@ -116,6 +116,9 @@ def lib():
     L.elfhip_net_param_count.argtypes = [C.POINTER(NetConfig)]
     L.elfhip_net_param_count.restype = C.c_longlong
     L.elfhip_net_load.argtypes = [vp, vp, C.c_longlong]
+    L.elfhip_net_load_device.argtypes = [vp, vp, C.c_longlong, C.c_longlong]
+    L.elfhip_net_version.argtypes = [vp]
+    L.elfhip_net_version.restype = C.c_longlong
     L.elfhip_net_forward.argtypes = [vp, vp, i, vp, vp, vp]
     L.elfhip_net_set_precision.argtypes = [vp, i]
     _lib = L

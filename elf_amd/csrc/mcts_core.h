@@ -667,9 +667,9 @@ struct MctsBase {
     }
     if (d.max_nodes > MAX_NODES_LIMIT) d.max_nodes = MAX_NODES_LIMIT;
     d.max_edges = opt->max_edges > 0 ? opt->max_edges : default_edges_per_node * d.max_nodes;
-    // spare arenas for treeAdvance: every tree at once while that is cheap, an eighth of the trees (eight launches
-    // per move) when the trees are what fills the GPU's memory
-    d.n_spare = n_trees <= 1024 ? n_trees : (n_trees / 8 > 1024 ? n_trees / 8 : 1024);
+    // spare arenas for treeAdvance: every tree at once while that is cheap, a sixteenth of the trees (sixteen
+    // launches per move) when the trees are what fills the GPU's memory
+    d.n_spare = n_trees <= 1024 ? n_trees : (n_trees / 16 > 1024 ? n_trees / 16 : 1024);
     if (const char* e = getenv("ELFHIP_MCTS_SPARE_ARENAS")) {   // tests: force the chunked advance on small searches
       const int v = atoi(e);
       if (v >= 1 && v <= n_trees) d.n_spare = v;

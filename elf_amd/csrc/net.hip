@@ -654,10 +654,10 @@ conv3x3_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, con
 template <class T>
 __global__ void __launch_bounds__(256)
 net_heads_kernel(const T* __restrict__ x, const T* __restrict__ xlo, int H, int W, int C, int A,
-                 const float* __restrict__ wpi, float bpi, const float* __restrict__ wv, float bv,
+                 const float* __restrict__ wpi, const float* __restrict__ hsc, const float* __restrict__ wv,
                  const float* __restrict__ pl_w, const float* __restrict__ pl_b,
                  const float* __restrict__ v1_w, const float* __restrict__ v1_b,
-                 const float* __restrict__ v2_w, float v2_b,
+                 const float* __restrict__ v2_w,
                  float* __restrict__ pi_out, float* __restrict__ logpi_out, float* __restrict__ v_out) {
   extern __shared__ float sm[];
   const int HW = H * W;
@@ -667,6 +667,7 @@ net_heads_kernel(const T* __restrict__ x, const T* __restrict__ xlo, int H, int 
   float* hid = logits + A;    // [256]
   __shared__ float red[8];
   const int n = blockIdx.x, tid = threadIdx.x;
+  const float bpi = hsc[0], bv = hsc[1], v2_b = hsc[2];   // folded biases of the two 1x1 convolutions, value_linear2.bias
   for (int p = tid; p < HW; p += 256) {
     const int y = p / W, xw = p % W;
     const size_t roff = (((size_t)n * (H + 2) + y + 1) * (W + 2) + xw + 1) * C;
@@ -731,6 +732,58 @@ net_heads_kernel(const T* __restrict__ x, const T* __restrict__ xlo, int H, int 
   if (tid == 0) v_out[n] = tanhf(red[0] + red[1] + red[2] + red[3] + v2_b);
 }
 
+// ---- weight preparation, on the device: the parameters arrive as ONE fp32 blob in the reference's state_dict order
+// (include/elfhip.h) - from the host (elfhip_net_load copies it up first) or already in HBM (elfhip_net_load_device:
+// what a weight broadcast over RCCL leaves behind).  Same float operations, in the same order, as a host loop would
+// do: scale = gamma / sqrt(var + eps); w' = bf16(w * scale); b' = (conv_bias - mean) * scale + beta.
+__device__ inline uint16_t f2bf_any(float f) { return f2bf(f); }
+// one 3x3 convolution + BatchNorm -> w [9][d][cp] bf16 (BN folded), wb [9][cp/32][d][32] bf16 (the board kernel's
+// stage-major copy), bias [d]; optionally the fp32 path's unfolded weights fw [9][d][cp] + scale / shift
+__global__ void net_prep_conv_kernel(const float* __restrict__ wt, const float* __restrict__ cb, const float* __restrict__ g,
+                                     const float* __restrict__ be, const float* __restrict__ mu, const float* __restrict__ var, float eps,
+                                     int d, int cin, int cp, uint16_t* __restrict__ w, uint16_t* __restrict__ wb, float* __restrict__ bias,
+                                     float* __restrict__ fw, float* __restrict__ fsc, float* __restrict__ fsh) {
+  const size_t total = (size_t)9 * d * cp;
+  const int nch = cp / KC;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % cp); const size_t r = i / cp;
+    const int co = (int)(r % d), t = (int)(r / d);
+    const float sc = g[co] / sqrtf(var[co] + eps);
+    const float raw = ci < cin ? wt[((size_t)co * cin + ci) * 9 + t] : 0.f;
+    const uint16_t q = ci < cin ? f2bf(raw * sc) : (uint16_t)0;
+    w[i] = q;
+    wb[(((size_t)t * nch + ci / KC) * d + co) * KC + ci % KC] = q;
+    if (fw) fw[i] = raw;
+    if (t == 0 && ci == 0) {
+      const float sh = (cb[co] - mu[co]) * sc + be[co];
+      bias[co] = sh;
+      if (fsc) { fsc[co] = sc; fsh[co] = sh; }
+    }
+  }
+}
+// the two 1x1 head convolutions (+ BN) -> folded weight vectors and biases; value_linear2.bias
+__global__ void net_prep_heads_kernel(const float* __restrict__ p, int d, float eps, float* __restrict__ wpi, float* __restrict__ wv,
+                                      float* __restrict__ hsc, const float* __restrict__ v2_bias) {
+  // section layout: weight [d], conv bias, gamma, beta, mean, var   (x2: policy, value)
+  for (int h = 0; h < 2; ++h) {
+    const float* q = p + (size_t)h * (d + 5);
+    const float cb = q[d], g = q[d + 1], be = q[d + 2], mu = q[d + 3], var = q[d + 4];
+    const float sc = g / sqrtf(var + eps);
+    float* dst = h == 0 ? wpi : wv;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < d; c += gridDim.x * blockDim.x) dst[c] = q[c] * sc;
+    if (blockIdx.x == 0 && threadIdx.x == 0) hsc[h] = (cb - mu) * sc + be;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) hsc[2] = v2_bias[0];
+}
+// Linear weight [out][in] -> [in][out] (the heads kernel's lanes are outputs: a wave reads one contiguous row)
+__global__ void net_transpose_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cols), r = (int)(i / cols);
+    dst[(size_t)c * rows + r] = src[i];
+  }
+}
+
 #define NALLOC(ptr, bytes)                                                                       \
   do {                                                                                           \
     if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) {                                      \
@@ -749,7 +802,8 @@ struct NetImpl {
   std::vector<void*> allocs;
   std::vector<ConvW> convs;  // stem + 2 per block
   float *wpi = nullptr, *wv = nullptr, *pl_w = nullptr, *pl_b = nullptr, *v1_w = nullptr, *v1_b = nullptr, *v2_w = nullptr;
-  float bpi = 0, bv = 0, v2_b = 0;
+  float* hsc = nullptr;            // {folded bias of pi_final_conv, of value_final_conv, value_linear2.bias}
+  long long version = -1;          // model version of the loaded weights (elfhip_net_load_device); -1 = unversioned
   uint16_t *xin = nullptr, *act[3] = {nullptr, nullptr, nullptr};
   // The skip stream (the stem's output and every block's output) carries 12 mantissa bits instead of bf16's 8:
   // act[] holds the value rounded to bf16 - what the next convolution's MFMAs read - and `lo` the next four bits
@@ -801,7 +855,7 @@ struct NetImpl {
       NALLOC(convs[i].b, (size_t)d * 4);
     }
     const size_t hw = (size_t)H * H;
-    NALLOC(wpi, d * 4); NALLOC(wv, d * 4);
+    NALLOC(wpi, d * 4); NALLOC(wv, d * 4); NALLOC(hsc, 4 * 4);
     NALLOC(pl_w, cfg.num_action * hw * 4); NALLOC(pl_b, cfg.num_action * 4);
     NALLOC(v1_w, 256 * hw * 4); NALLOC(v1_b, 256 * 4); NALLOC(v2_w, 256 * 4);
     return ELFHIP_OK;
@@ -824,88 +878,51 @@ struct NetImpl {
     return ELFHIP_OK;
   }
 
-  int load_f32(const float* h) {
-    const int d = cfg.dim;
-    const float* p = h;
-    for (size_t li = 0; li < fconvs.size(); ++li) {
-      const int cin = li == 0 ? cfg.planes : d, cp = fconvs[li].cin;
-      const float* wt = p; p += (size_t)d * cin * 9;
-      const float* cb = p; p += d;
-      const float *g = p, *be = p + d, *mu = p + 2 * d, *var = p + 3 * d; p += 4 * d;
-      std::vector<float> wq((size_t)9 * d * cp, 0.f), sc(d), sh(d);
-      for (int co = 0; co < d; ++co) {
-        sc[co] = g[co] / std::sqrt(var[co] + cfg.bn_eps);
-        sh[co] = (cb[co] - mu[co]) * sc[co] + be[co];
-        for (int ci = 0; ci < cin; ++ci)
-          for (int t = 0; t < 9; ++t) wq[((size_t)t * d + co) * cp + ci] = wt[((size_t)co * cin + ci) * 9 + t];
-      }
-      HIPCHECK(hipMemcpy(fconvs[li].w, wq.data(), wq.size() * 4, hipMemcpyHostToDevice));
-      HIPCHECK(hipMemcpy(fconvs[li].sc, sc.data(), (size_t)d * 4, hipMemcpyHostToDevice));
-      HIPCHECK(hipMemcpy(fconvs[li].sh, sh.data(), (size_t)d * 4, hipMemcpyHostToDevice));
-    }
-    return ELFHIP_OK;
-  }
-
-  // h = flat fp32 parameters in the reference's state_dict order (see elfhip.h); folds BN, casts to bf16
-  int load(const float* h, size_t n) {
+  // h_or_d = flat fp32 parameters in the reference's state_dict order (see elfhip.h), on the host or on this device
+  int load(const float* params, size_t n, bool on_device, long long ver) {
     if (n != param_count()) { elfhip_set_error("net_load: expected %zu floats, got %zu", param_count(), n); return ELFHIP_EINVAL; }
-    if (f32) { int rc = load_f32(h); if (rc) return rc; }
+    const float* blob = params;
+    float* tmp = nullptr;
+    if (!on_device) {
+      if (hipMalloc((void**)&tmp, n * 4) != hipSuccess) { elfhip_set_error("net_load: device allocation of %zu bytes failed", n * 4); return ELFHIP_ENOMEM; }
+      hipError_t e = hipMemcpyAsync(tmp, params, n * 4, hipMemcpyHostToDevice, stream);
+      if (e != hipSuccess) { (void)hipFree(tmp); HIPCHECK(e); }
+      blob = tmp;
+    }
     const int d = cfg.dim, H = cfg.board;
     const size_t hw = (size_t)H * H;
-    auto bf = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
-    const float* p = h;
+    const float* p = blob;
     for (size_t li = 0; li < convs.size(); ++li) {
       const int cin = li == 0 ? cfg.planes : d, cp = convs[li].cin;
       const float* wt = p; p += (size_t)d * cin * 9;
       const float* cb = p; p += d;
       const float *g = p, *be = p + d, *mu = p + 2 * d, *var = p + 3 * d; p += 4 * d;
-      std::vector<uint16_t> wq((size_t)9 * d * cp, 0);
-      std::vector<float> bq(d);
-      for (int co = 0; co < d; ++co) {
-        const float sc = g[co] / std::sqrt(var[co] + cfg.bn_eps);
-        bq[co] = (cb[co] - mu[co]) * sc + be[co];
-        for (int ci = 0; ci < cin; ++ci)
-          for (int t = 0; t < 9; ++t) wq[((size_t)t * d + co) * cp + ci] = bf(wt[((size_t)co * cin + ci) * 9 + t] * sc);
-      }
-      HIPCHECK(hipMemcpy(convs[li].w, wq.data(), wq.size() * 2, hipMemcpyHostToDevice));
-      {  // the board kernel's copy: stage-major, one stage = COUT x 32 channels contiguous
-        std::vector<uint16_t> wb(wq.size());
-        const int nch = cp / KC;
-        for (int t = 0; t < 9; ++t)
-          for (int co = 0; co < d; ++co)
-            for (int ci = 0; ci < cp; ++ci)
-              wb[(((size_t)t * nch + ci / KC) * d + co) * KC + ci % KC] = wq[((size_t)t * d + co) * cp + ci];
-        HIPCHECK(hipMemcpy(convs[li].wb, wb.data(), wb.size() * 2, hipMemcpyHostToDevice));
-      }
-      HIPCHECK(hipMemcpy(convs[li].b, bq.data(), bq.size() * 4, hipMemcpyHostToDevice));
+      const size_t total = (size_t)9 * d * cp;
+      hipLaunchKernelGGL(net_prep_conv_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, stream, wt, cb, g, be,
+                         mu, var, cfg.bn_eps, d, cin, cp, convs[li].w, convs[li].wb, convs[li].b,
+                         f32 ? fconvs[li].w : (float*)nullptr, f32 ? fconvs[li].sc : (float*)nullptr, f32 ? fconvs[li].sh : (float*)nullptr);
     }
-    auto head1x1 = [&](float* dw, float& db) -> int {
-      const float* wt = p; p += d;
-      const float cb = *p++; const float g = p[0], be = p[1], mu = p[2], var = p[3]; p += 4;
-      const float sc = g / std::sqrt(var + cfg.bn_eps);
-      std::vector<float> wf(d);
-      for (int c = 0; c < d; ++c) wf[c] = wt[c] * sc;
-      db = (cb - mu) * sc + be;
-      HIPCHECK(hipMemcpy(dw, wf.data(), (size_t)d * 4, hipMemcpyHostToDevice));
-      return ELFHIP_OK;
-    };
-    int rc = head1x1(wpi, bpi); if (rc) return rc;
-    rc = head1x1(wv, bv); if (rc) return rc;
-    {  // stored transposed ([point][action]): the heads kernel's lanes are actions, so a wave reads one contiguous row
-      std::vector<float> t((size_t)cfg.num_action * hw);
-      for (int a = 0; a < cfg.num_action; ++a) for (int q = 0; q < hw; ++q) t[(size_t)q * cfg.num_action + a] = p[(size_t)a * hw + q];
-      HIPCHECK(hipMemcpy(pl_w, t.data(), t.size() * 4, hipMemcpyHostToDevice)); p += cfg.num_action * hw;
+    const float* heads = p; p += 2 * (d + 5);
+    const float* plw = p; p += (size_t)cfg.num_action * hw;
+    const float* plb = p; p += cfg.num_action;
+    const float* v1w = p; p += 256 * hw;
+    const float* v1b = p; p += 256;
+    const float* v2w = p; p += 256;
+    const float* v2b = p; p += 1;
+    hipLaunchKernelGGL(net_prep_heads_kernel, dim3(1), dim3(256), 0, stream, heads, d, cfg.bn_eps, wpi, wv, hsc, v2b);
+    hipLaunchKernelGGL(net_transpose_kernel, dim3(256), dim3(256), 0, stream, plw, cfg.num_action, (int)hw, pl_w);
+    hipLaunchKernelGGL(net_transpose_kernel, dim3(256), dim3(256), 0, stream, v1w, 256, (int)hw, v1_w);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(pl_b, plb, (size_t)cfg.num_action * 4, hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(v1_b, v1b, 256 * 4, hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(v2_w, v2w, 256 * 4, hipMemcpyDeviceToDevice, stream);
+    if (tmp) {   // the staging copy must outlive the kernels that read it
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      (void)hipFree(tmp);
     }
-    HIPCHECK(hipMemcpy(pl_b, p, cfg.num_action * 4, hipMemcpyHostToDevice)); p += cfg.num_action;
-    {  // likewise [point][hidden unit]
-      std::vector<float> t((size_t)256 * hw);
-      for (int a = 0; a < 256; ++a) for (int q = 0; q < hw; ++q) t[(size_t)q * 256 + a] = p[(size_t)a * hw + q];
-      HIPCHECK(hipMemcpy(v1_w, t.data(), t.size() * 4, hipMemcpyHostToDevice)); p += 256 * hw;
-    }
-    HIPCHECK(hipMemcpy(v1_b, p, 256 * 4, hipMemcpyHostToDevice)); p += 256;
-    HIPCHECK(hipMemcpy(v2_w, p, 256 * 4, hipMemcpyHostToDevice)); p += 256;
-    v2_b = *p++;
+    HIPCHECK(e);
     loaded = true;
+    version = ver;
     return ELFHIP_OK;
   }
 
@@ -1002,8 +1019,8 @@ struct NetImpl {
       cur = t2;
     }
     const size_t sm = ((size_t)2 * H * H + cfg.num_action + 256) * 4;
-    hipLaunchKernelGGL(net_heads_kernel<float>, dim3(B), dim3(256), sm, stream, fact[cur], (const float*)nullptr, H, H, cfg.dim, cfg.num_action, wpi, bpi,
-                       wv, bv, pl_w, pl_b, v1_w, v1_b, v2_w, v2_b, d_pi, d_logpi, d_v);
+    hipLaunchKernelGGL(net_heads_kernel<float>, dim3(B), dim3(256), sm, stream, fact[cur], (const float*)nullptr, H, H, cfg.dim, cfg.num_action, wpi, hsc,
+                       wv, pl_w, pl_b, v1_w, v1_b, v2_w, d_pi, d_logpi, d_v);
     HIPCHECK(hipGetLastError());
     return ELFHIP_OK;
   }
@@ -1026,8 +1043,8 @@ struct NetImpl {
     const size_t sm = ((size_t)2 * H * H + cfg.num_action + 256) * 4;
     // the generic kernel's `lo` is a second bf16 array the heads can add; the board kernel's nibbles are private to it
     const uint16_t* const hlo = board_shape() ? nullptr : slo;
-    hipLaunchKernelGGL(net_heads_kernel<uint16_t>, dim3(B), dim3(256), sm, stream, act[cur], hlo, H, H, cfg.dim, cfg.num_action, wpi, bpi, wv,
-                       bv, pl_w, pl_b, v1_w, v1_b, v2_w, v2_b, d_pi, d_logpi, d_v);
+    hipLaunchKernelGGL(net_heads_kernel<uint16_t>, dim3(B), dim3(256), sm, stream, act[cur], hlo, H, H, cfg.dim, cfg.num_action, wpi, hsc, wv,
+                       pl_w, pl_b, v1_w, v1_b, v2_w, d_pi, d_logpi, d_v);
     HIPCHECK(hipGetLastError());
     return ELFHIP_OK;
   }
@@ -1107,8 +1124,16 @@ int elfhip_net_set_precision(elfhip_net* h, int dtype) {
 int elfhip_net_load(elfhip_net* h, const float* h_params, long long n_params) {
   CHECK_N(h);
   if (!h_params) { elfhip_set_error("net_load: null params"); return ELFHIP_EINVAL; }
-  return h->n->load(h_params, (size_t)n_params);
+  return h->n->load(h_params, (size_t)n_params, false, -1);
 }
+
+int elfhip_net_load_device(elfhip_net* h, const float* d_params, long long n_params, long long version) {
+  CHECK_N(h);
+  if (!d_params) { elfhip_set_error("net_load_device: null params"); return ELFHIP_EINVAL; }
+  return h->n->load(d_params, (size_t)n_params, true, version);
+}
+
+long long elfhip_net_version(const elfhip_net* h) { return (h && h->n) ? h->n->version : -1; }
 
 int elfhip_net_forward(elfhip_net* h, const float* d_s, int batch, float* d_pi, float* d_logpi, float* d_v) {
   CHECK_N(h);

@@ -20,14 +20,35 @@ def shard_games(total_games, rank, world):
     return lo, lo + per + (1 if rank < rem else 0)
 
 
+def _host_staged(t, group):
+    """gloo moves host memory: a CUDA tensor goes through a host copy there (the one-GPU rehearsals); with RCCL
+    ("nccl") the tensor itself is the collective's buffer and nothing leaves HBM."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def broadcast_weights(flat, version, src=0, group=None):
     """flat: 1-D tensor (any dtype) with the same numel on every rank.  Returns (flat, version)."""
-    hdr = torch.tensor([int(version), flat.numel()], dtype=torch.int64, device=flat.device)
+    staged = _host_staged(flat, group)
+    hdr = torch.tensor([int(version), flat.numel()], dtype=torch.int64, device="cpu" if staged else flat.device)
     dist.broadcast(hdr, src=src, group=group)
     if int(hdr[1].item()) != flat.numel():
         raise RuntimeError("broadcast_weights: blob size mismatch (%d vs %d)" % (int(hdr[1].item()), flat.numel()))
-    dist.broadcast(flat, src=src, group=group)
+    if staged:
+        h = flat.cpu()
+        dist.broadcast(h, src=src, group=group)
+        flat.copy_(h)
+    else:
+        dist.broadcast(flat, src=src, group=group)
     return flat, int(hdr[0].item())
+
+
+def update_model(net, flat, version, src=0, group=None):
+    """The self-play side of a model update (replaces selfplay.py:81-92,214-236's reload from the shared filesystem):
+    every rank passes its fp32 CUDA buffer of net.param_count() floats - on `src` holding the trainer's new weights
+    in pack_state_dict order - and ends up with those weights loaded (elfhip_net_load_device) under `version`."""
+    flat, version = broadcast_weights(flat, version, src=src, group=group)
+    net.load_device(flat, version)
+    return version
 
 
 def gather_records(slab, dst=0, group=None):
@@ -39,6 +60,9 @@ def gather_records(slab, dst=0, group=None):
     names = sorted(slab.keys())
     k = slab[names[0]].shape[0] if names else 0
     dev = slab[names[0]].device if names else torch.device("cpu")
+    if names and _host_staged(slab[names[0]], group):
+        slab = {n: v.cpu() for n, v in slab.items()}
+        dev = torch.device("cpu")
     cnt = torch.tensor([k], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(counts, cnt, group=group)

@@ -98,6 +98,18 @@ class PolicyValueNet:
     def set_stream(self, stream):
         check(self.L.elfhip_net_set_stream(self.h, C.c_void_p(stream.cuda_stream if stream is not None else 0)))
 
+    def param_count(self):
+        return int(self.L.elfhip_net_param_count(C.byref(self.cfg)))
+
+    def load_device(self, flat, version=-1):
+        """flat: fp32 CUDA tensor holding the state_dict blob (pack_state_dict order), e.g. the buffer a weight
+        broadcast filled; the weights are prepared by kernels, nothing crosses PCIe."""
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.numel() == self.param_count()
+        check(self.L.elfhip_net_load_device(self.h, flat.data_ptr(), flat.numel(), int(version)))
+
+    def version(self):
+        return int(self.L.elfhip_net_version(self.h))
+
     def load_state_dict(self, sd):
         blob = pack_state_dict(sd, self.cfg.num_block)
         assert blob.size == self.L.elfhip_net_param_count(C.byref(self.cfg)), (blob.size,)

@@ -17,6 +17,11 @@ from .boards import BoardBatch
 from .mcts import TreeSearchBatch
 
 
+def dist_backend_is_device(group=None):
+    import torch.distributed as dist
+    return dist.get_backend(group) == "nccl"
+
+
 class GameRng:
     """n std::mt19937 streams, one per game: the reference's GameBase::_rng (common/GameBase.h:43-49,76).  With
     GameOptions.seed != 0 every game is seeded with it (as in the reference); seed == 0 is time-based there, here a
@@ -133,3 +138,31 @@ class SelfPlayBatch:
     def take_records(self):
         out, self.finished = self.finished, []
         return out
+
+    # ---- the two collectives of the path (elf_amd/dist.py) ----------------------------------------
+    def update_model(self, flat, version, src=0, group=None):
+        """A new model from the trainer rank: broadcast (RCCL over xGMI on the node) + device-side load.  The trees
+        are cleared like ClientGameSelfPlay::restart does on UPDATE_MODEL (ClientGameSelfPlay.cc:198-247)."""
+        from . import dist as edist
+        v = edist.update_model(self.net, flat, version, src=src, group=group)
+        self.ts.clear()
+        return v
+
+    def send_records(self, dst=0, group=None, first_game_id=0):
+        """Finished games of this rank -> the trainer rank (replaces JSON over ZMQ, DistriClient.h:104-122): the
+        fixed-stride slabs since the last call, game ids shifted to this rank's shard.  Returns on `dst` the
+        concatenated slabs of all ranks (dict of tensors), elsewhere None."""
+        from . import dist as edist
+        slabs = self.take_records()
+        names = ["game_id", "seq", "n_moves", "reward", "moves", "values"] + (["policies"] if self.policies is not None else [])
+        if slabs:
+            cat = {k: torch.from_numpy(np.concatenate([s[k] for s in slabs])) for k in names}
+        else:
+            shapes = dict(game_id=((0,), torch.int32), seq=((0,), torch.int64), n_moves=((0,), torch.int32), reward=((0,), torch.float32),
+                          moves=((0, self.max_ply), torch.int16), values=((0, self.max_ply), torch.float32),
+                          policies=((0, self.max_ply, self.A), torch.uint8))
+            cat = {k: torch.zeros(shapes[k][0], dtype=shapes[k][1]) for k in names}
+        cat["game_id"] = cat["game_id"] + int(first_game_id)
+        if dist_backend_is_device(group):
+            cat = {k: v.to(self.device) for k, v in cat.items()}
+        return edist.gather_records(cat, dst=dst, group=group)

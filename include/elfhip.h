@@ -244,7 +244,7 @@ int elfhip_mcts_advance(elfhip_mcts* m, const int16_t* d_actions);
 int elfhip_mcts_stats(elfhip_mcts* m, unsigned long long* h_stats4, int32_t* d_flags);
 /* Device bytes one tree's arena takes (node records + node states + edges) with this handle's max_nodes /
  * max_edges; the handle holds n_trees + n_spare such arenas (n_spare = n_trees up to 1,024 trees, else
- * max(1024, n_trees / 8): treeAdvance's destinations).  No reference counterpart (its nodes live on the heap):
+ * max(1024, n_trees / 16): treeAdvance's destinations).  No reference counterpart (its nodes live on the heap):
  * a sizing aid for callers that fill a GPU with trees.  h_n_arenas (nullable) receives the arena count. */
 long long elfhip_mcts_tree_bytes(const elfhip_mcts* m, int* h_n_arenas);
 
@@ -286,6 +286,14 @@ long long elfhip_net_param_count(const elfhip_net_config* cfg);
  * reference's own non-FP16Model mode, utils/fp16_utils.py:31-43 off).  Call before elfhip_net_load. */
 int elfhip_net_set_precision(elfhip_net* n, int dtype);
 int elfhip_net_load(elfhip_net* n, const float* h_params, long long n_params);
+/* The same blob already in this device's memory - what a weight broadcast over RCCL leaves behind (it replaces the
+ * reference's reload of save-<ver>.bin from a shared filesystem, scripts/elfgames/american_checkers/py/selfplay.py:
+ * 81-92,214-236): BatchNorm folding, bf16 conversion and the kernels' weight layouts are produced by kernels on the
+ * handle's stream, nothing crosses PCIe.  `version` is the model version the blob carries (the reference parses it
+ * from the file name, selfplay.py:65-70); elfhip_net_version returns it (-1 after a plain elfhip_net_load) so the
+ * caller can stamp its replies ("rv", trainer.py:146-147). */
+int elfhip_net_load_device(elfhip_net* n, const float* d_params, long long n_params, long long version);
+long long elfhip_net_version(const elfhip_net* n);
 /* d_s: float [batch][planes][board][board] (the "s" key); outputs float: d_pi [batch][num_action],
  * d_logpi (nullable) same shape, d_v [batch]. */
 int elfhip_net_forward(elfhip_net* n, const float* d_s, int batch, float* d_pi, float* d_logpi, float* d_v);

@@ -1,0 +1,100 @@
+"""The two collectives of the path wired into the self-play driver, two ranks on ONE GPU over gloo (the rehearsal
+mode: a one-GPU box cannot form an RCCL communicator; on the 8-GPU node the same calls run on "nccl" = RCCL and the
+buffers stay in HBM):
+  SelfPlayBatch.update_model  = broadcast of the trainer rank's weight blob + version, then elfhip_net_load_device
+                                (replaces the reload of save-<ver>.bin, selfplay.py:81-92,214-236);
+  SelfPlayBatch.send_records  = finished-game slabs of every rank gathered on the trainer rank
+                                (replaces JSON over ZMQ, DistriClient.h:104-122).
+Both ranks must answer the same input with bit-identical pi / V after the broadcast (rank 1 started from other
+weights), and rank 0 must receive exactly the games both ranks finished, ids shifted into each rank's shard."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from elf_amd import dist as edist
+        from elf_amd.boards import AMERICAN
+        from elf_amd.net import PolicyValueNet, pack_state_dict
+        from elf_amd.selfplay import SelfPlayBatch
+        from oracle.model_ref import seeded_model
+        cfg = dict(planes=36, board=8, dim=32, num_block=2, num_action=170)
+        n = 8
+        net = PolicyValueNet(max_batch=n * 4, **cfg)
+        net.load_state_dict(seeded_model(seed=10 + rank, **cfg).state_dict())       # every rank its own stale model
+        assert net.version() == -1
+        sp = SelfPlayBatch(AMERICAN, n, net=net, num_rollouts_per_thread=16, num_rollouts_per_batch=4, virtual_loss=1, c_puct=1.5)
+        x = (torch.rand((6, 36, 8, 8), generator=torch.Generator().manual_seed(3)) < 0.3).float().cuda()
+        before = net.forward(x)["pi"].cpu().numpy().tobytes()
+        flat = torch.zeros(net.param_count(), dtype=torch.float32, device="cuda")
+        if rank == 0:   # the trainer rank holds version 5
+            flat.copy_(torch.from_numpy(pack_state_dict(seeded_model(seed=1, **cfg).state_dict(), cfg["num_block"])))
+        ver = sp.update_model(flat, 5 if rank == 0 else -1, src=0)
+        out = net.forward(x)
+        after = out["pi"].cpu().numpy().tobytes() + out["V"].cpu().numpy().tobytes()
+        # the device-side load equals the host-side load of the same blob
+        net2 = PolicyValueNet(max_batch=n * 4, **cfg)
+        net2.load_state_dict(seeded_model(seed=1, **cfg).state_dict())
+        o2 = net2.forward(x)
+        same_as_host_load = after == o2["pi"].cpu().numpy().tobytes() + o2["V"].cpu().numpy().tobytes()
+        lo, hi = edist.shard_games(world * n, rank, world)
+        finished = 0
+        got = None
+        for rnd in range(2):
+            for _ in range(200):
+                finished += sp.step()
+                if sp.win_stats["total_games"] >= (rnd + 1) * 3:
+                    break
+            g = sp.send_records(dst=0, first_game_id=lo)
+            if rank == 0:
+                got = g if got is None else {k: torch.cat([got[k], g[k]]) for k in g}
+            else:
+                assert g is None
+        q.put(dict(rank=rank, ver=ver, net_ver=net.version(), before=hashlib.sha1(before).hexdigest(), after=hashlib.sha1(after).hexdigest(),
+                   same_as_host_load=same_as_host_load, finished=finished, shard=(lo, hi),
+                   got=None if got is None else {k: v.cpu().numpy() for k, v in got.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_a_model_and_return_their_records():
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in procs], key=lambda o: o["rank"])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    r0, r1 = outs
+    assert r0["ver"] == r1["ver"] == 5 and r0["net_ver"] == r1["net_ver"] == 5
+    assert r0["before"] != r1["before"]                  # they started from different models
+    assert r0["after"] == r1["after"]                    # and answer bit-identically after the broadcast
+    assert r0["same_as_host_load"] and r1["same_as_host_load"]
+    got = r0["got"]
+    assert r1["got"] is None
+    assert len(got["game_id"]) == r0["finished"] + r1["finished"] and r0["finished"] >= 3 and r1["finished"] >= 3
+    in0 = (got["game_id"] >= r0["shard"][0]) & (got["game_id"] < r0["shard"][1])
+    in1 = (got["game_id"] >= r1["shard"][0]) & (got["game_id"] < r1["shard"][1])
+    assert int(in0.sum()) == r0["finished"] and int(in1.sum()) == r1["finished"]
+    nm = got["n_moves"]
+    assert (nm > 0).all() and got["moves"].shape == (len(nm), 250) and got["policies"].shape == (len(nm), 250, 170)
+    for i in range(len(nm)):
+        assert (got["moves"][i, : nm[i]] >= 0).all() and (got["moves"][i, nm[i]:] == -1).all()
+    assert set(np.unique(got["reward"])) <= {-1.0, 1.0}
