@@ -22,7 +22,7 @@ SYMBOLS = [
     "elfhip_boards_playout", "elfhip_test_sort_order", "elfhip_test_umap_order", "elfhip_test_umap_order_wave", "elfhip_test_find_move", "elfhip_gather_rows", "elfhip_scatter_rows",
     "elfhip_mcts_create", "elfhip_mcts_destroy", "elfhip_mcts_set_stream", "elfhip_mcts_clear", "elfhip_mcts_set_roots",
     "elfhip_mcts_run_uniform", "elfhip_mcts_select", "elfhip_mcts_backup", "elfhip_mcts_result", "elfhip_mcts_advance",
-    "elfhip_mcts_stats", "elfhip_mcts_tree_bytes", "elfhip_mcts_pick_moves", "elfhip_mcts_seed_rng", "elfhip_mcts_root_noise",
+    "elfhip_mcts_stats", "elfhip_mcts_tree_bytes", "elfhip_mcts_pick_moves", "elfhip_mcts_seed_rng", "elfhip_mcts_seed_pick_rng", "elfhip_mcts_root_noise",
     "elfhip_mcts_set_active", "elfhip_mcts_pick_policy_only",
     "elfhip_net_create", "elfhip_net_destroy", "elfhip_net_set_stream", "elfhip_net_param_count", "elfhip_net_load", "elfhip_net_load_device", "elfhip_net_version",
     "elfhip_net_forward", "elfhip_net_set_precision",
@@ -32,7 +32,7 @@ SYMBOLS = [
 
 class NetConfig(C.Structure):
     _fields_ = [("planes", C.c_int), ("board", C.c_int), ("dim", C.c_int), ("num_block", C.c_int),
-                ("num_action", C.c_int), ("bn_eps", C.c_float)]
+                ("num_action", C.c_int), ("bn_eps", C.c_float), ("leaky_slope", C.c_float)]
 
 
 class TSOptions(C.Structure):
@@ -89,6 +89,7 @@ def lib():
     L.elfhip_mcts_create.argtypes = [i, i, C.POINTER(TSOptions), i, C.POINTER(vp)]
     L.elfhip_mcts_destroy.argtypes = [vp]
     L.elfhip_mcts_seed_rng.argtypes = [vp, vp]
+    L.elfhip_mcts_seed_pick_rng.argtypes = [vp, C.c_uint32]
     L.elfhip_mcts_root_noise.argtypes = [vp, C.c_float, C.c_float]
     L.elfhip_gather_rows.argtypes = [vp, C.c_longlong, vp, i, vp, i, vp]
     L.elfhip_scatter_rows.argtypes = [vp, C.c_longlong, vp, i, vp, i, vp]

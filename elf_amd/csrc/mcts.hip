@@ -319,7 +319,7 @@ int elfhip_mcts_create(int game, int n_trees, const elfhip_ts_options* opt, int 
     elfhip_set_error("mcts_create: num_rollouts_per_batch=%d not in [1,%d]", opt->num_rollouts_per_batch, mcts::MAXB);
     return ELFHIP_EINVAL;
   }
-  if (opt->num_rollouts_per_thread < 1 || opt->virtual_loss < 0 || opt->pick_method < 0 || opt->pick_method > 1) {
+  if (opt->num_rollouts_per_thread < 1 || opt->virtual_loss < 0 || opt->pick_method < 0 || opt->pick_method > 2) {
     elfhip_set_error("mcts_create: bad rollouts / virtual_loss / pick_method");
     return ELFHIP_EINVAL;
   }
@@ -355,8 +355,11 @@ int elfhip_mcts_set_roots(elfhip_mcts* h, elfhip_boards* b, uint8_t* d_ok) {
     elfhip_set_error("mcts_set_roots: boards handle must be of the search's game with n == n_trees on the same device");
     return ELFHIP_EINVAL;
   }
+  if (int rc = h->m->draw_pick_indices()) return rc;
   return h->m->set_roots(b->slab, d_ok);
 }
+
+int elfhip_mcts_seed_pick_rng(elfhip_mcts* h, uint32_t seed) { CHECK_M(h); h->m->pick_rng.seed(seed); return ELFHIP_OK; }
 
 int elfhip_mcts_seed_rng(elfhip_mcts* h, const uint32_t* h_seeds) { CHECK_M(h); return h->m->seed_rng(h_seeds); }
 
@@ -388,8 +391,9 @@ int elfhip_mcts_result(elfhip_mcts* h, int16_t* d_best, int32_t* d_total_visits,
   CHECK_M(h);
   if (edge_cap < 0) { elfhip_set_error("mcts_result: negative edge_cap"); return ELFHIP_EINVAL; }
   mcts::MctsBase* m = h->m;
+  if (m->o.pick == 2 && !m->d_rnd) { elfhip_set_error("mcts_result: uniform_random needs set_roots first"); return ELFHIP_ESTATE; }
   hipLaunchKernelGGL(mcts::mcts_result_kernel, dim3(m->d.n_trees), dim3(64), 0, m->stream, m->d, m->num_actions, m->o.pick,
-                     d_best, d_total_visits, d_best_q, d_root_value, d_n_edges, d_edge_action, d_edge_visits, d_edge_reward,
+                     (const uint32_t*)m->d_rnd, d_best, d_total_visits, d_best_q, d_root_value, d_n_edges, d_edge_action, d_edge_visits, d_edge_reward,
                      d_edge_prior, edge_cap, d_policy_visits);
   HIPCHECK(hipGetLastError());
   return ELFHIP_OK;
@@ -400,7 +404,9 @@ int elfhip_mcts_pick_moves(elfhip_mcts* h, const int32_t* d_ply, int policy_dist
   CHECK_M(h);
   if (!d_move) { elfhip_set_error("mcts_pick_moves: null d_move"); return ELFHIP_EINVAL; }
   mcts::MctsBase* m = h->m;
-  hipLaunchKernelGGL(mcts::mcts_pick_kernel, dim3(m->d.n_trees), dim3(64), 0, m->stream, m->d, m->num_actions, d_ply,
+  if (m->o.pick == 2 && !m->d_rnd) { elfhip_set_error("mcts_pick_moves: uniform_random needs set_roots first"); return ELFHIP_ESTATE; }
+  hipLaunchKernelGGL(mcts::mcts_pick_kernel, dim3(m->d.n_trees), dim3(64), 0, m->stream, m->d, m->num_actions, m->o.pick,
+                     (const uint32_t*)m->d_rnd, d_ply,
                      policy_distri_cutoff, d_canonical, d_move, d_policy_u8, d_value);
   HIPCHECK(hipGetLastError());
   return ELFHIP_OK;

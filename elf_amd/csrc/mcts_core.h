@@ -8,6 +8,7 @@
 // tree_search_base.h:175-201,310-367, elfgames/american_checkers/mcts/MCTSGameActor.h:198-335.
 #pragma once
 #include <stdlib.h>
+#include <time.h>
 #include <cmath>
 #include <new>
 #include <random>
@@ -393,7 +394,7 @@ static __global__ void __launch_bounds__(64) mcts_set_active_kernel(TreeDev d, c
 // chooseAction + MCTSResultT::addActions (tree_search.h:588-621, tree_search_base.h:310-367) and
 // MCTSGameAI::getValue (MCTSGameAI.h:40-46).  Edges are reported in iteration order.
 static __global__ void __launch_bounds__(64)
-mcts_result_kernel(TreeDev d, int NA, int pick, int16_t* __restrict__ best_out, int32_t* __restrict__ total_out,
+mcts_result_kernel(TreeDev d, int NA, int pick, const uint32_t* __restrict__ rnd, int16_t* __restrict__ best_out, int32_t* __restrict__ total_out,
                    float* __restrict__ bestq_out, float* __restrict__ rootv_out, int32_t* __restrict__ nedges_out,
                    int16_t* __restrict__ ea_out, int32_t* __restrict__ ev_out, float* __restrict__ er_out,
                    float* __restrict__ ep_out, int cap, int32_t* __restrict__ policy_out) {
@@ -410,7 +411,7 @@ mcts_result_kernel(TreeDev d, int NA, int pick, int16_t* __restrict__ best_out, 
     int visits = 0; float score = -INFINITY;
     if (ok) {
       visits = edge_visits(tv, eb + j);
-      score = pick == 0 ? (float)visits : tv.ep[eb + j];
+      score = pick == 0 ? (float)visits : (pick == 1 ? tv.ep[eb + j] : 1.0f);
       if (j < cap) {
         if (ea_out) ea_out[(size_t)t * cap + j] = (int16_t)tv.ea[eb + j];
         if (ev_out) ev_out[(size_t)t * cap + j] = visits;
@@ -429,6 +430,7 @@ mcts_result_kernel(TreeDev d, int NA, int pick, int16_t* __restrict__ best_out, 
     if (s > best || (s == best && sj < bestj)) { best = s; bestj = sj; }
     total += tv_sum;
   }
+  if (pick == 2 && ne > 0) bestj = (int)(rnd[t] % (uint32_t)ne);   // UNIFORM_RANDOM: random_idx = rng() % size (tree_search_base.h:322-326)
   if (lane == 0) {
     const float rootv = tv.V[0];
     if (ne == 0) {
@@ -451,9 +453,12 @@ mcts_result_kernel(TreeDev d, int NA, int pick, int16_t* __restrict__ best_out, 
 // multiplies by its range): float rd = canon * Z with Z the float sum of the normalised policy in edge order; the
 // move is the first edge whose running float sum exceeds rd, the last edge when none does.
 static __global__ void __launch_bounds__(64)
-mcts_pick_kernel(TreeDev d, int NA, const int32_t* __restrict__ ply, int cutoff, const double* __restrict__ canon,
-                 int16_t* __restrict__ move, uint8_t* __restrict__ pol, float* __restrict__ value) {
-  __shared__ int s_vis[512];
+mcts_pick_kernel(TreeDev d, int NA, int pick, const uint32_t* __restrict__ rnd, const int32_t* __restrict__ ply, int cutoff,
+                 const double* __restrict__ canon, int16_t* __restrict__ move, uint8_t* __restrict__ pol, float* __restrict__ value) {
+  // the policy's scores depend on the rank criterion (MCTSResultT::addActions, tree_search_base.h:328-333): visit
+  // counts for most_visited, priors for strongest_prior, 1 for uniform_random
+  __shared__ float s_sc[512];
+  __shared__ float s_sum;
   const int t = blockIdx.x, lane = threadIdx.x;
   if (d.t_flags[t] & FLAG_INACTIVE) return;  // the other AI's handle fills this game's outputs
   TV tv = tree_view(d, t);
@@ -462,41 +467,57 @@ mcts_pick_kernel(TreeDev d, int NA, const int32_t* __restrict__ ply, int cutoff,
   const int eb = (int)tv.ebase[0];
   if (pol) for (int a = lane; a < NA; a += 64) pol[(size_t)t * NA + a] = 0;
   __syncthreads();
-  // pass 1: totals, most-visited edge (first strict max in edge order)
-  int total = 0, bestv = -1, bestj = 0x7FFFFFFF;
+  // pass 1: total visits, best edge (first strict max of the score in edge order)
+  int total = 0, bestj = 0x7FFFFFFF;
+  float bests = -INFINITY;
   for (int base = 0; base < ne; base += 64) {
     const int j = base + lane;
-    int v = j < ne ? edge_visits(tv, eb + j) : -1, vj = j < ne ? j : 0x7FFFFFFF, sum = j < ne ? v : 0;
-    if (j < ne && j < 512) s_vis[j] = v;
+    const int vis = j < ne ? edge_visits(tv, eb + j) : 0;
+    float v = j < ne ? (pick == 0 ? (float)vis : (pick == 1 ? tv.ep[eb + j] : 1.0f)) : -INFINITY;
+    int vj = j < ne ? j : 0x7FFFFFFF, sum = vis;
+    if (j < ne && j < 512) s_sc[j] = v;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-      int v2 = __shfl_xor(v, off), j2 = __shfl_xor(vj, off);
+      float v2 = __shfl_xor(v, off); int j2 = __shfl_xor(vj, off);
       if (v2 > v || (v2 == v && j2 < vj)) { v = v2; vj = j2; }
       sum += __shfl_xor(sum, off);
     }
-    if (v > bestv || (v == bestv && vj < bestj)) { bestv = v; bestj = vj; }
+    if (v > bests || (v == bests && vj < bestj)) { bests = v; bestj = vj; }
     total += sum;
+  }
+  if (pick == 2 && ne > 0) bestj = (int)(rnd[t] % (uint32_t)ne);
+  __syncthreads();
+  // MCTSPolicy::normalize: exp_sum = float sum of the scores in edge order (visit counts and ones sum exactly)
+  if (lane == 0) {
+    float es = 0.0f;
+    if (pick == 1) for (int j = 0; j < ne; ++j) es += s_sc[j]; else es = pick == 0 ? (float)total : (float)ne;
+    s_sum = es;
   }
   __syncthreads();
   const bool diverse = ply && canon && ply[t] <= cutoff && ne > 0;
-  const float exp_sum = (float)total, maxp = total > 0 ? (float)bestv / exp_sum : 0.f;   // visit counts sum exactly in float
+  const float exp_sum = s_sum;
+  float maxp = 0.0f;   // addMCTSPolicy: max_val = max(0, p_j)
+  for (int j = lane; j < ne; j += 64) maxp = fmaxf(maxp, s_sc[j] / exp_sum);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) maxp = fmaxf(maxp, __shfl_xor(maxp, off));
+  const bool have = pick == 0 ? total > 0 : ne > 0;   // no visit at all: 0 / 0 scores, recorded as zeros
   if (pol) {
     for (int j = lane; j < ne; j += 64) {
-      const float p = (float)s_vis[j] / exp_sum;
+      const float p = s_sc[j] / exp_sum;
       const float q = p / maxp * 255.0f;
-      pol[(size_t)t * NA + tv.ea[eb + j]] = total > 0 ? (uint8_t)q : 0;
+      pol[(size_t)t * NA + tv.ea[eb + j]] = have ? (uint8_t)q : 0;
     }
   }
   if (lane == 0) {
     int chosen = ne > 0 ? bestj : -1;
     if (diverse) {   // one lane: the two float sums are sequential in edge order
       float Z = 0.0f;
-      for (int j = 0; j < ne; ++j) Z += (float)s_vis[j] / exp_sum;
+      for (int j = 0; j < ne; ++j) Z += s_sc[j] / exp_sum;
       const float rd = (float)(canon[t] * ((double)Z - 0.0) + 0.0);
       float accu = 0.0f;
       chosen = ne - 1;
       for (int j = 0; j < ne; ++j) {
-        accu = (float)s_vis[j] / exp_sum + accu;
+        accu = s_sc[j] / exp_sum + accu;
         if (rd < accu) { chosen = j; break; }
       }
     }
@@ -764,6 +785,21 @@ struct MctsBase {
   }
   size_t bytes_per_tree() const {
     return (size_t)d.max_nodes * (NODE_BYTES + 4 * (size_t)d.state_words) + (size_t)d.max_edges * EDGE_BYTES;
+  }
+  // pick_method "uniform_random" (MCTSResultT::addActions, tree_search_base.h:321-326: `static std::mt19937
+  // rng(time(NULL)); random_idx = rng() % size`): one draw per tree and move, made when the move's roots are set, so
+  // that elfhip_mcts_result and elfhip_mcts_pick_moves report the same action.  Time-seeded like the reference's
+  // (elfhip_mcts_seed_pick_rng makes it repeatable for tests).
+  std::mt19937 pick_rng{(uint32_t)time(nullptr)};
+  uint32_t* d_rnd = nullptr;
+  int draw_pick_indices() {
+    if (o.pick != 2) return ELFHIP_OK;
+    if (!d_rnd) MCTS_ALLOC(d_rnd, (size_t)d.n_trees * 4);
+    std::vector<uint32_t> r((size_t)d.n_trees);
+    for (auto& x : r) x = (uint32_t)pick_rng();
+    HIPCHECK(hipMemcpyAsync(d_rnd, r.data(), r.size() * 4, hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    return ELFHIP_OK;
   }
   int clear(const uint8_t* d_which) {
     hipLaunchKernelGGL(mcts_clear_kernel, dim3(d.n_trees), dim3(64), 0, stream, d, d_which);

@@ -40,6 +40,9 @@ __device__ inline uint32_t pack_bf16(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
+// nn.ReLU, or nn.LeakyReLU(slope) when the model was built with --leaky_relu (model_american_checkers.py:51,204: 0.1)
+__device__ inline float act_relu(float v, float slope) { return slope == 0.f ? fmaxf(v, 0.f) : fmaxf(v, v * slope); }
+
 constexpr int KC = 32;        // input channels per K step
 constexpr int LROW = 40;      // LDS row stride in bf16 (32 data + 8 pad = 80 B)
 constexpr int BP = 128;       // positions per workgroup
@@ -62,7 +65,7 @@ __global__ void net_pack_input_kernel(const float* __restrict__ s, uint16_t* __r
 template <int COUT>
 __global__ void __launch_bounds__(256)
 conv3x3_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
-               const uint16_t* __restrict__ res, uint16_t* __restrict__ out, uint16_t* lo, int lo_in, int B, int H, int W, int CIN, int relu) {
+               const uint16_t* __restrict__ res, uint16_t* __restrict__ out, uint16_t* lo, int lo_in, int B, int H, int W, int CIN, int relu, float slope) {
   constexpr int MT = COUT / 16;  // output-channel tiles
   __shared__ __attribute__((aligned(16))) uint16_t sW[COUT * LROW];
   __shared__ __attribute__((aligned(16))) uint16_t sX[BP * LROW];
@@ -137,7 +140,7 @@ conv3x3_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, c
       }
       if (relu) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        for (int r = 0; r < 4; ++r) v[r] = act_relu(v[r], slope);
       }
       uint2 o;
       o.x = pack_bf16(v[0], v[1]);
@@ -238,7 +241,7 @@ __device__ inline void lds_dma16(const char* gsrc, const char* lds_dst) {
 template <int COUT, int H, int NBW, int SPLIT>
 __global__ void __launch_bounds__(512)
 conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
-                     const uint16_t* __restrict__ res, uint16_t* __restrict__ out, uint16_t* lo, int B, int CIN, int relu,
+                     const uint16_t* __restrict__ res, uint16_t* __restrict__ out, uint16_t* lo, int B, int CIN, int relu, float slope,
                      int late_half, int stagger, int phases) {
   constexpr int PW = H + 2, PP = PW * PW, HW = H * H;
   constexpr int PT = NBW * HW;             // output positions of this workgroup
@@ -510,7 +513,7 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
           }
           if (relu) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            for (int r = 0; r < 4; ++r) v[r] = act_relu(v[r], slope);
           }
           if (SPLIT) {
             // v rounded to 20 bits (12 dropped, half up), then to bf16 (half up again): the bf16 word goes to the
@@ -576,7 +579,7 @@ template <int COUT>
 __global__ void __launch_bounds__(256)
 conv3x3_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int B, int H, int W,
-                   int CIN, int relu) {
+                   int CIN, int relu, float slope) {
   constexpr int MT = COUT / 16;
   __shared__ __attribute__((aligned(16))) float sW[COUT * FROW];
   __shared__ __attribute__((aligned(16))) float sX[BP * FROW];
@@ -642,7 +645,7 @@ conv3x3_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, con
       }
       if (relu) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        for (int r = 0; r < 4; ++r) v[r] = act_relu(v[r], slope);
       }
       *(float4*)(out + obase + co) = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -667,7 +670,7 @@ net_heads_kernel(const T* __restrict__ x, const T* __restrict__ xlo, int H, int 
   float* hid = logits + A;    // [256]
   __shared__ float red[8];
   const int n = blockIdx.x, tid = threadIdx.x;
-  const float bpi = hsc[0], bv = hsc[1], v2_b = hsc[2];   // folded biases of the two 1x1 convolutions, value_linear2.bias
+  const float bpi = hsc[0], bv = hsc[1], v2_b = hsc[2], slope = hsc[3];   // folded biases of the two 1x1 convolutions, value_linear2.bias
   for (int p = tid; p < HW; p += 256) {
     const int y = p / W, xw = p % W;
     const size_t roff = (((size_t)n * (H + 2) + y + 1) * (W + 2) + xw + 1) * C;
@@ -688,8 +691,8 @@ net_heads_kernel(const T* __restrict__ x, const T* __restrict__ xlo, int H, int 
         }
       }
     }
-    fpi[p] = fmaxf(a + bpi, 0.f);
-    fv[p] = fmaxf(b + bv, 0.f);
+    fpi[p] = act_relu(a + bpi, slope);
+    fv[p] = act_relu(b + bv, slope);
   }
   __syncthreads();
   for (int a = tid; a < A; a += 256) {
@@ -702,7 +705,7 @@ net_heads_kernel(const T* __restrict__ x, const T* __restrict__ xlo, int H, int 
     float acc = v1_b[tid];
     const float* wr = v1_w + tid;                     // [HW][256]
     for (int p = 0; p < HW; ++p) acc += wr[(size_t)p * 256] * fv[p];
-    hid[tid] = fmaxf(acc, 0.f);
+    hid[tid] = act_relu(acc, slope);
   }
   __syncthreads();
   // log-softmax over A
@@ -763,7 +766,7 @@ __global__ void net_prep_conv_kernel(const float* __restrict__ wt, const float* 
 }
 // the two 1x1 head convolutions (+ BN) -> folded weight vectors and biases; value_linear2.bias
 __global__ void net_prep_heads_kernel(const float* __restrict__ p, int d, float eps, float* __restrict__ wpi, float* __restrict__ wv,
-                                      float* __restrict__ hsc, const float* __restrict__ v2_bias) {
+                                      float* __restrict__ hsc, const float* __restrict__ v2_bias, float slope) {
   // section layout: weight [d], conv bias, gamma, beta, mean, var   (x2: policy, value)
   for (int h = 0; h < 2; ++h) {
     const float* q = p + (size_t)h * (d + 5);
@@ -773,7 +776,7 @@ __global__ void net_prep_heads_kernel(const float* __restrict__ p, int d, float 
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < d; c += gridDim.x * blockDim.x) dst[c] = q[c] * sc;
     if (blockIdx.x == 0 && threadIdx.x == 0) hsc[h] = (cb - mu) * sc + be;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) hsc[2] = v2_bias[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { hsc[2] = v2_bias[0]; hsc[3] = slope; }
 }
 // Linear weight [out][in] -> [in][out] (the heads kernel's lanes are outputs: a wave reads one contiguous row)
 __global__ void net_transpose_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
@@ -909,7 +912,7 @@ struct NetImpl {
     const float* v1b = p; p += 256;
     const float* v2w = p; p += 256;
     const float* v2b = p; p += 1;
-    hipLaunchKernelGGL(net_prep_heads_kernel, dim3(1), dim3(256), 0, stream, heads, d, cfg.bn_eps, wpi, wv, hsc, v2b);
+    hipLaunchKernelGGL(net_prep_heads_kernel, dim3(1), dim3(256), 0, stream, heads, d, cfg.bn_eps, wpi, wv, hsc, v2b, cfg.leaky_slope);
     hipLaunchKernelGGL(net_transpose_kernel, dim3(256), dim3(256), 0, stream, plw, cfg.num_action, (int)hw, pl_w);
     hipLaunchKernelGGL(net_transpose_kernel, dim3(256), dim3(256), 0, stream, v1w, 256, (int)hw, v1_w);
     hipError_t e = hipGetLastError();
@@ -930,7 +933,7 @@ struct NetImpl {
   void launch_conv(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, uint16_t* lo, int lo_in, int B, int relu) {
     const int M = B * cfg.board * cfg.board;
     hipLaunchKernelGGL(conv3x3_kernel<COUT>, dim3((M + BP - 1) / BP), dim3(256), 0, stream, x, c.w, c.b, res, out, lo, lo_in, B,
-                       cfg.board, cfg.board, c.cin, relu);
+                       cfg.board, cfg.board, c.cin, relu, cfg.leaky_slope);
   }
   // start offset per phase = 1/8 of the estimated cycles per board group (stages x MFMAs of the two waves of a
   // SIMD x 16 cycles x the measured ~2.1 ratio of loop time to matrix time): 22k cycles for the Go tower
@@ -953,7 +956,7 @@ struct NetImpl {
     const int ngroups = (B + NBW - 1) / NBW;
     const int grid = persist_wgs > 0 ? std::min(ngroups, persist_wgs) : ngroups;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, x, c.wb, c.b, res, out, lo, B, c.cin,
-                       relu, late_half, stagger >= 0 ? stagger : default_stagger<COUT, H, NBW>(c.cin), stagger_phases);
+                       relu, cfg.leaky_slope, late_half, stagger >= 0 ? stagger : default_stagger<COUT, H, NBW>(c.cin), stagger_phases);
     return ELFHIP_OK;
   }
   template <int COUT>
@@ -995,7 +998,7 @@ struct NetImpl {
   void launch_conv_f32(const float* x, const ConvF& c, const float* res, float* out, int B, int relu) {
     const int M = B * cfg.board * cfg.board;
     hipLaunchKernelGGL(conv3x3_f32_kernel<COUT>, dim3((M + BP - 1) / BP), dim3(256), 0, stream, x, c.w, c.sc, c.sh, res, out, B,
-                       cfg.board, cfg.board, c.cin, relu);
+                       cfg.board, cfg.board, c.cin, relu, cfg.leaky_slope);
   }
   void conv_f32(const float* x, const ConvF& c, const float* res, float* out, int B, int relu) {
     switch (cfg.dim) {
@@ -1065,7 +1068,7 @@ int elfhip_net_create(const elfhip_net_config* cfg, int max_batch, int device, e
   *out = nullptr;
   const bool dim_ok = cfg->dim == 32 || cfg->dim == 64 || cfg->dim == 128 || cfg->dim == 224 || cfg->dim == 256;
   if (!dim_ok || cfg->planes < 1 || cfg->planes > 64 || cfg->board < 3 || cfg->board > 19 || cfg->num_block < 0 ||
-      cfg->num_block > 64 || cfg->num_action < 1 || cfg->num_action > 1024 || max_batch < 1 || max_batch > (1 << 20)) {
+      cfg->num_block > 64 || cfg->num_action < 1 || cfg->num_action > 1024 || max_batch < 1 || max_batch > (1 << 20) || !(cfg->leaky_slope >= 0.f && cfg->leaky_slope < 1.f)) {
     elfhip_set_error("net_create: unsupported config (dim must be 32/64/128/224/256, board 3..19, planes <= 64)");
     return ELFHIP_EINVAL;
   }

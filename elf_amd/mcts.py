@@ -22,7 +22,7 @@ class TreeSearchBatch:
         self.R = int(num_rollouts_per_thread)
         self.device = torch.device("cuda", device)
         self.info = _lib.game_info(game)
-        pick = {"most_visited": 0, "strongest_prior": 1}[pick_method]
+        pick = {"most_visited": 0, "strongest_prior": 1, "uniform_random": 2}[pick_method]
         self.opt = TSOptions(self.R, self.B, int(virtual_loss), int(use_prior), float(c_puct), int(unexplored_q_zero),
                              int(root_unexplored_q_zero), int(persistent_tree), pick, int(max_nodes), int(max_edges))
         h = C.c_void_p()

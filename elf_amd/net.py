@@ -73,9 +73,11 @@ def random_state_dict(planes, board, dim, num_block, num_action, seed=0, **_):
 
 
 class PolicyValueNet:
-    def __init__(self, planes=36, board=8, dim=128, num_block=10, num_action=170, bn_eps=1e-5, max_batch=4096, device=0, precision="bf16"):
+    def __init__(self, planes=36, board=8, dim=128, num_block=10, num_action=170, bn_eps=1e-5, max_batch=4096, device=0, precision="bf16",
+                 leaky_relu=False):
+        """leaky_relu: the reference model's --leaky_relu option (nn.LeakyReLU(0.1) in place of every nn.ReLU)"""
         self.L = _lib.lib()
-        self.cfg = NetConfig(planes, board, dim, num_block, num_action, bn_eps)
+        self.cfg = NetConfig(planes, board, dim, num_block, num_action, bn_eps, 0.1 if leaky_relu else 0.0)
         self.max_batch = max_batch
         self.device = torch.device("cuda", device)
         h = C.c_void_p()

@@ -569,7 +569,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
   // num_rollouts_per_thread rollouts on one "thread" (results are only defined run-to-run for num_threads == 1).
   void build_ais() {
     const TSOptions& t = req_.mcts_opt;
-    if (t.pick_method != "most_visited" && t.pick_method != "strongest_prior")
+    if (t.pick_method != "most_visited" && t.pick_method != "strongest_prior" && t.pick_method != "uniform_random")
       throw std::range_error("MCTS Pick method unknown! " + t.pick_method);  // tree_search.h:615
     const int threads = t.num_threads > 0 ? t.num_threads : 1;
     AiSpec a1{"actor_black", req_.black_ver, t.alg_opt.c_puct, t.num_rollouts_per_thread * threads, t.num_rollouts_per_batch};
@@ -602,7 +602,7 @@ class SelfPlayEngine : public elfhip_py::Engine {
     for (int k = 0; k < n_ai_; ++k) {
       elfhip_ts_options o{spec_[k].R, spec_[k].B, t.virtual_loss, t.alg_opt.use_prior ? 1 : 0, spec_[k].c_puct,
                           t.alg_opt.unexplored_q_zero ? 1 : 0, t.alg_opt.root_unexplored_q_zero ? 1 : 0,
-                          t.persistent_tree ? 1 : 0, t.pick_method == "most_visited" ? 0 : 1, 0, 0};
+                          t.persistent_tree ? 1 : 0, t.pick_method == "most_visited" ? 0 : (t.pick_method == "strongest_prior" ? 1 : 2), 0, 0};
       ck(elfhip_mcts_create(game_, n_, &o, device_, &mcts_[k]), "mcts_create");
       // init_ai hands every new AI the game rng's next draw as MCTSActorParams::seed (ClientGameSelfPlay.cc:59):
       // first draw -> "actor_black", second -> "actor_white", whatever player_swap does to the pointers afterwards

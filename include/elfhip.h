@@ -144,7 +144,7 @@ typedef struct {
   int unexplored_q_zero;       /* alg_opt.unexplored_q_zero */
   int root_unexplored_q_zero;  /* alg_opt.root_unexplored_q_zero */
   int persistent_tree;
-  int pick_method;             /* 0 "most_visited", 1 "strongest_prior" */
+  int pick_method;             /* 0 "most_visited", 1 "strongest_prior", 2 "uniform_random" (tree_search.h:588-621) */
   int max_nodes;               /* per tree per arena; 0 = 8*rollouts+64 */
   int max_edges;               /* per tree per arena; 0 = 12*max_nodes */
 } elfhip_ts_options;
@@ -170,6 +170,10 @@ int elfhip_mcts_set_roots(elfhip_mcts* m, elfhip_boards* b, uint8_t* d_ok);
  * elfhip_mcts_seed_rng: h_seeds u32 [n_trees] (nullable = all 0) re-seeds the per-tree generators
  * (MCTSActorParams::seed, MCTSGameActor.h; the reference draws them from the game's own rng). */
 int elfhip_mcts_seed_rng(elfhip_mcts* m, const uint32_t* h_seeds);
+/* pick_method "uniform_random": the reference draws the index of the reported action from one process-wide
+ * `static std::mt19937 rng(time(NULL))` (tree_search_base.h:321-326); here each handle owns such a generator,
+ * time-seeded too, and draws one index per tree whenever a move's roots are set.  This call re-seeds it (tests). */
+int elfhip_mcts_seed_pick_rng(elfhip_mcts* m, uint32_t seed);
 int elfhip_mcts_root_noise(elfhip_mcts* m, float root_epsilon, float root_alpha);
 /* TreeSearchT::run with the uniform evaluator (pi = 1/num_actions before filtering, V = 0, terminal
  * +-1): all ceil(rollouts/batch) batches inside ONE launch.  BASELINE.json configs[2]. */
@@ -191,7 +195,8 @@ int elfhip_mcts_result(elfhip_mcts* m, int16_t* d_best, int32_t* d_total_visits,
                        int32_t* d_n_edges, int16_t* d_edge_action, int32_t* d_edge_visits, float* d_edge_reward,
                        float* d_edge_prior, int edge_cap, int32_t* d_policy_visits);
 /* Move choice and record values of the self-play loop (ClientGameSelfPlay.cc:94-122):
- *   policy = MCTSGameAI::getMCTSPolicy (visit counts normalised, MCTSGameAI.h:48-54);
+ *   policy = MCTSGameAI::getMCTSPolicy (the rank criterion's scores normalised, MCTSGameAI.h:48-54: visit counts
+ *     for most_visited, priors for strongest_prior, ones for uniform_random - tree_search_base.h:328-333);
  *   d_policy_u8 (nullable) u8 [n][num_actions] = GameStateExt::addMCTSPolicy quantisation
  *     uchar(p / max_p * 255)  (GameStateExt.h:79-100);
  *   d_value (nullable) f32 [n] = MCTSGameAI::getValue (best edge Q, or root V when unvisited);
@@ -272,6 +277,8 @@ typedef struct {
   int num_block;
   int num_action;  /* checkers_num_action (170) / 362 */
   float bn_eps;    /* 1e-5 */
+  float leaky_slope; /* 0 = nn.ReLU; the reference's --leaky_relu option is nn.LeakyReLU(0.1) for every activation of
+                        the model (model_american_checkers.py:51,204); 0 <= slope < 1 */
 } elfhip_net_config;
 
 typedef struct elfhip_net elfhip_net;

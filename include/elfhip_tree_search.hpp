@@ -77,13 +77,14 @@ class TreeSearchBatchT {
 
   TreeSearchBatchT(int game, int n_trees, const TSOptions& o, int device = 0) : n_(n_trees), device_(device), opt_(o) {
     check(elfhip_game_get_info(game, &gi_), "game_get_info");
-    if (o.pick_method != "most_visited" && o.pick_method != "strongest_prior")
+    if (o.pick_method != "most_visited" && o.pick_method != "strongest_prior" && o.pick_method != "uniform_random")
       throw std::range_error("MCTS Pick method unknown! " + o.pick_method);  // tree_search.h:615
-    rank_ = o.pick_method == "most_visited" ? MCTSResult::MOST_VISITED : MCTSResult::PRIOR;
+    rank_ = o.pick_method == "most_visited" ? MCTSResult::MOST_VISITED
+                                            : (o.pick_method == "strongest_prior" ? MCTSResult::PRIOR : MCTSResult::UNIFORM_RANDOM);
     B_ = o.num_rollouts_per_batch;
     R_ = o.num_rollouts_per_thread * (o.num_threads > 0 ? o.num_threads : 1);
     elfhip_ts_options t{R_, B_, o.virtual_loss, o.alg_opt.use_prior ? 1 : 0, o.alg_opt.c_puct, o.alg_opt.unexplored_q_zero ? 1 : 0,
-                        o.alg_opt.root_unexplored_q_zero ? 1 : 0, o.persistent_tree ? 1 : 0, rank_ == MCTSResult::PRIOR ? 1 : 0, 0, 0};
+                        o.alg_opt.root_unexplored_q_zero ? 1 : 0, o.persistent_tree ? 1 : 0, (int)rank_, 0, 0};
     check(elfhip_mcts_create(game, n_trees, &t, device, &h_), "mcts_create");
     hip(hipSetDevice(device), "hipSetDevice");
     const size_t slots = (size_t)n_ * B_, plane = (size_t)gi_.num_planes * gi_.board_size * gi_.board_size;
@@ -178,8 +179,10 @@ class TreeSearchBatchT {
         e.prior_probability = ep[(size_t)i * cap_ + j]; e.reward = er[(size_t)i * cap_ + j]; e.num_visits = ev[(size_t)i * cap_ + j];
         const Action a = (Action)ea[(size_t)i * cap_ + j];
         r.action_edge_pairs.emplace_back(a, e);
-        const float score = rank_ == MCTSResult::MOST_VISITED ? (float)e.num_visits : e.prior_probability;
-        if (score > r.max_score) { r.max_score = score; r.best_action = a; r.best_edge_info = e; }
+        const float score = rank_ == MCTSResult::MOST_VISITED ? (float)e.num_visits : (rank_ == MCTSResult::PRIOR ? e.prior_probability : 1.0f);
+        if (rank_ == MCTSResult::UNIFORM_RANDOM) {   // the library drew the index (tree_search_base.h:321-326)
+          if (a == (Action)best[i]) { r.max_score = score; r.best_action = a; r.best_edge_info = e; }
+        } else if (score > r.max_score) { r.max_score = score; r.best_action = a; r.best_edge_info = e; }
       }
       if (ne[i] > 0 && r.best_action != (Action)best[i]) throw std::logic_error("result: host and device ranking disagree");
     }

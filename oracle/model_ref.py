@@ -11,18 +11,22 @@ import torch
 import torch.nn as nn
 
 
-def _conv_layer(cin, cout, kernel=3, relu=True, eps=1e-5, momentum=0.1):
+def _act(leaky):  # :51,204  self.relu = nn.LeakyReLU(0.1) if self.options.leaky_relu else nn.ReLU()
+    return nn.LeakyReLU(0.1) if leaky else nn.ReLU()
+
+
+def _conv_layer(cin, cout, kernel=3, relu=True, eps=1e-5, momentum=0.1, leaky=False):
     layers = [nn.Conv2d(cin, cout, kernel, padding=kernel // 2), nn.BatchNorm2d(cout, momentum=momentum, eps=eps)]
     if relu:
-        layers.append(nn.ReLU())
+        layers.append(_act(leaky))
     return nn.Sequential(*layers)
 
 
 class Block(nn.Module):  # :21-90
-    def __init__(self, dim, eps):
+    def __init__(self, dim, eps, leaky=False):
         super().__init__()
-        self.relu = nn.ReLU()
-        self.conv_lower = _conv_layer(dim, dim, eps=eps)
+        self.relu = _act(leaky)
+        self.conv_lower = _conv_layer(dim, dim, eps=eps, leaky=leaky)
         self.conv_upper = _conv_layer(dim, dim, relu=False, eps=eps)
 
     def forward(self, s):
@@ -31,29 +35,29 @@ class Block(nn.Module):  # :21-90
 
 
 class GoResNet(nn.Module):  # :102-125
-    def __init__(self, dim, num_block, eps):
+    def __init__(self, dim, num_block, eps, leaky=False):
         super().__init__()
-        self.resnet = nn.Sequential(*[Block(dim, eps) for _ in range(num_block)])
+        self.resnet = nn.Sequential(*[Block(dim, eps, leaky) for _ in range(num_block)])
 
     def forward(self, s):
         return self.resnet(s)
 
 
 class ModelPolicyValue(nn.Module):  # :137-349
-    def __init__(self, planes=36, board=8, dim=128, num_block=10, num_action=170, bn_eps=1e-5):
+    def __init__(self, planes=36, board=8, dim=128, num_block=10, num_action=170, bn_eps=1e-5, leaky_relu=False):
         super().__init__()
         self.board = board
-        self.relu = nn.ReLU()
-        self.init_conv = _conv_layer(planes, dim, eps=bn_eps)
-        self.pi_final_conv = _conv_layer(dim, 1, kernel=1, eps=bn_eps)
-        self.value_final_conv = _conv_layer(dim, 1, kernel=1, eps=bn_eps)
+        self.relu = _act(leaky_relu)
+        self.init_conv = _conv_layer(planes, dim, eps=bn_eps, leaky=leaky_relu)
+        self.pi_final_conv = _conv_layer(dim, 1, kernel=1, eps=bn_eps, leaky=leaky_relu)
+        self.value_final_conv = _conv_layer(dim, 1, kernel=1, eps=bn_eps, leaky=leaky_relu)
         d = board * board
         self.pi_linear = nn.Linear(d, num_action)
         self.value_linear1 = nn.Linear(d, 256)
         self.value_linear2 = nn.Linear(256, 1)
         self.logsoftmax = nn.LogSoftmax(dim=1)
         self.tanh = nn.Tanh()
-        self.resnet = GoResNet(dim, num_block, bn_eps)
+        self.resnet = GoResNet(dim, num_block, bn_eps, leaky_relu)
 
     def forward(self, s):  # :325-349
         s = self.resnet(self.init_conv(s))

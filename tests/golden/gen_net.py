@@ -19,6 +19,8 @@ CONFIGS = {
     "go_2x32": dict(planes=18, board=19, dim=32, num_block=2, num_action=362),
     "go_4x224": dict(planes=18, board=19, dim=224, num_block=4, num_action=362),
     "go_20x224": dict(planes=18, board=19, dim=224, num_block=20, num_action=362),   # BASELINE.json configs[3]
+    "checkers_4x64_leaky": dict(planes=36, board=8, dim=64, num_block=4, num_action=170, leaky_relu=True),   # --leaky_relu
+    "go_2x32_leaky": dict(planes=18, board=19, dim=32, num_block=2, num_action=362, leaky_relu=True),
 }
 
 
@@ -56,7 +58,7 @@ def main():
             with torch.no_grad():
                 xt = torch.from_numpy(x)
                 t = m.resnet(m.init_conv(xt))
-                alive = min(float((m.pi_final_conv(t) > 0).float().mean()), float((m.value_final_conv(t) > 0).float().mean()))
+                alive = 1.0 if cfg.get("leaky_relu") else min(float((m.pi_final_conv(t) > 0).float().mean()), float((m.value_final_conv(t) > 0).float().mean()))
                 o = m(xt)
             if alive >= 0.3:
                 break
@@ -64,7 +66,7 @@ def main():
             raise SystemExit("no seed with live heads for " + name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "net_%s.npz" % name),
                             x=np.packbits(x.astype(np.uint8), axis=None), x_shape=np.array(x.shape),
-                            pi=o["pi"].numpy(), V=o["V"].numpy(), seed=np.array(seed), cfg=np.array([cfg[k] for k in ("planes", "board", "dim", "num_block", "num_action")]),
+                            pi=o["pi"].numpy(), V=o["V"].numpy(), seed=np.array(seed), cfg=np.array([cfg[k] for k in ("planes", "board", "dim", "num_block", "num_action")]), leaky=np.array(int(bool(cfg.get("leaky_relu")))),
                             meta=np.array(["torch %s CPU fp32; oracle/model_ref.py seeded_model(seed=%d)" % (torch.__version__, seed)]))
         print(name, "seed", seed, x.shape, float(o["pi"].max()), float(o["V"].abs().max()))
 

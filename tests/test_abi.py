@@ -51,7 +51,7 @@ def test_random_state_dict_matches_the_documented_parameter_layout():
         sd = random_state_dict(seed=3, **cfg)
         assert set(sd) == set(state_dict_order(cfg["num_block"]))
         blob = pack_state_dict(sd, cfg["num_block"])
-        c = _lib.NetConfig(cfg["planes"], cfg["board"], cfg["dim"], cfg["num_block"], cfg["num_action"], 1e-5)
+        c = _lib.NetConfig(cfg["planes"], cfg["board"], cfg["dim"], cfg["num_block"], cfg["num_action"], 1e-5, 0.0)
         assert blob.size == L.elfhip_net_param_count(C.byref(c))
         sd2 = random_state_dict(seed=3, **cfg)
         assert all((sd[k] == sd2[k]).all() for k in sd)      # seeded: reproducible

@@ -255,3 +255,49 @@ def test_root_noise_matches_oracle(torch_cuda):
     assert differ
     _, flags = ts.stats()
     assert not flags.cpu().numpy().any()
+
+
+def test_rank_criteria_prior_and_uniform_random(torch_cuda):
+    """pick_method decides the reported action AND the policy's scores (MCTSResultT::addActions, tree_search_base.h:
+    310-367): strongest_prior = the priors, uniform_random = ones with the action at index rng() % n_edges (one
+    std::mt19937 draw per tree and move)."""
+    import ctypes as C
+    torch = torch_cuda
+    from elf_amd.boards import BoardBatch, AMERICAN
+    from elf_amd.mcts import TreeSearchBatch
+    from elf_amd._lib import check
+    L = _oracle.oracle()
+    n = 24
+    bb = BoardBatch(AMERICAN, n)
+    bb.playout(9, seed=5)
+    for method in ("uniform_random", "strongest_prior"):
+        ts = TreeSearchBatch(AMERICAN, n, num_rollouts_per_thread=32, num_rollouts_per_batch=4, virtual_loss=1, c_puct=1.5, pick_method=method)
+        check(ts.L.elfhip_mcts_seed_pick_rng(ts.h, 99))
+        ply = torch.ones(n, dtype=torch.int32, device="cuda")
+        rng = L.orng_create(99)
+        for mv in range(2):
+            assert ts.set_roots(bb).cpu().numpy().all()
+            ts.run_uniform()
+            res = {k: v.cpu().numpy() for k, v in ts.result(edge_cap=64).items()}
+            move = torch.empty(n, dtype=torch.int16, device="cuda")
+            pol = torch.empty((n, 170), dtype=torch.uint8, device="cuda")
+            check(ts.L.elfhip_mcts_pick_moves(ts.h, ply.data_ptr(), 0, None, move.data_ptr(), pol.data_ptr(), None))
+            move, pol = move.cpu().numpy(), pol.cpu().numpy()
+            for i in range(n):
+                k = int(res["n_edges"][i])
+                acts = res["edge_action"][i, :k]
+                if method == "uniform_random":
+                    want = int(acts[L.orng_next_u32(rng) % k])
+                    assert (pol[i, acts] == 255).all() and int(pol[i].astype(np.int64).sum()) == 255 * k
+                else:
+                    pr = res["edge_prior"][i, :k]
+                    want = int(acts[int(np.argmax(pr))])            # first maximum in edge order
+                    p = pr / np.float32(np.add.reduce(pr.astype(np.float32)))
+                    assert pol[i, want] == 255
+                assert int(res["best"][i]) == want and int(move[i]) == want, (method, mv, i)
+            act = torch.tensor(move, device="cuda")
+            bb2_ok = bb.forward(act)
+            assert bb2_ok.cpu().numpy().all()
+            ts.treeAdvance(act)
+        L.orng_destroy(rng)
+        bb.reset(); bb.playout(9, seed=5)
