@@ -444,10 +444,142 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
     // Output addressing: wave-uniform base pointers of this board group + 32-bit per-lane element
     // offsets, derived here from pb (through an opaque copy: hoisted out of the board loop they would
     // sit in registers - or in scratch - across the whole main loop).
-    bool live[NTW];
-    uint32_t obase[NTW];
     const uint16_t* const resg = res ? res + (size_t)xrow0 * COUT : nullptr;
     uint16_t* const outg = out + (size_t)xrow0 * COUT;
+    // STAGED epilogue: the accumulator layout gives a lane 4 channels of one position per tile, i.e. 8-byte pieces
+    // 32 bytes apart - as global accesses that is 32 lines touched per wave instruction.  Instead each position tile
+    // (16 positions x this wave's 16*MTW channels) goes through a private staging area in LDS - the activation buffer
+    // of the chunk that was just finished is dead until the next board's third stage pair - so that global memory
+    // sees 16-byte-per-lane accesses over contiguous 32*MTW-byte runs, for the skip loads as well as the stores.
+    constexpr int ROWB = 32 * MTW + 16;                 // staged row: 16*MTW bf16 channels + 16 bytes of padding
+    // Only where the accumulators leave registers for it: the 19x19 x 224 tile keeps 168 of the 256 VGPRs in
+    // accumulators and the staging's chunk registers then spill into the main loop (measured: 410 -> 524 ms per
+    // 32,768 Go positions), so that shape keeps the direct epilogue below; 8x8 x 128 gains 7 %.
+    constexpr bool STAGED = 8 * 16 * ROWB <= XBYTES && MTW * NTW * 4 <= 96;
+    if constexpr (STAGED) {
+      constexpr int CH = 2 * MTW;                       // 16-byte chunks per staged row
+      constexpr int NCH = 16 * CH, NK = (NCH + 63) / 64;
+      constexpr int LW = (MTW + 1) / 2;                 // words of skip-stream nibbles per lane and position tile
+      char* const stg = sX + ((gchunk & 1) ^ 1) * XBYTES + wave * (16 * ROWB);
+      uint32_t* const log = SPLIT ? (uint32_t*)lo + ((size_t)g * 8 + wave) * NTW * 64 * LW : nullptr;   // [nt][lane][LW]
+      uint32_t ob[NTW];                                 // element offset of this lane's position's row; ~0 = no such position
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int p = (wp * NTW + nt) * 16 + r16;
+        uint32_t pbv = (uint32_t)pb[nt];
+        asm volatile("" : "+v"(pbv));
+        ob[nt] = (p < PT && board0 + p / HW < B) ? (pbv / 80u + (PW + 1)) * COUT : 0xFFFFFFFFu;
+      }
+      // bias first, one channel tile at a time: (acc + bias) + skip, the same float operations as before
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        const float4 bv = *(const float4*)(bias + (wc * MTW + mt) * 16 + q * 4);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) { acc[mt][nt][0] += bv.x; acc[mt][nt][1] += bv.y; acc[mt][nt][2] += bv.z; acc[mt][nt][3] += bv.w; }
+      }
+      // chunk c = k * 64 + lane of the staged tile: row c / CH (a position), 16-byte column c % CH
+      // (recomputed at every use from an opaque copy of the lane id: a handful of VALU against twelve registers
+      // held across the whole epilogue, which the accumulators leave no room for)
+      struct Chunk { uint32_t row, soff, goff; };
+      auto chunk = [&](int k) -> Chunk {
+        uint32_t l = (uint32_t)lane;
+        asm volatile("" : "+v"(l));
+        const uint32_t c = (uint32_t)(k * 64) + l;
+        const uint32_t row = c / (uint32_t)CH, col = c - row * (uint32_t)CH;
+        return Chunk{c < (uint32_t)NCH ? row : 0xFFu, row * ROWB + col * 16, (uint32_t)(wc * MTW * 16) + col * 8};
+      };
+      auto row_base = [&](int nt, const Chunk& ck) -> uint32_t {   // the offset held by the lane whose position is this chunk's row
+        const uint32_t o = (uint32_t)__shfl((int)ob[nt], (int)(ck.row & 15u));
+        return ck.row == 0xFFu ? 0xFFFFFFFFu : o;
+      };
+      uint4 rg[NK];
+      uint32_t lw[LW];
+      auto fetch = [&](int nt) {
+        if (res) {
+#pragma unroll
+          for (int k = 0; k < NK; ++k) {
+            const Chunk ck = chunk(k);
+            const uint32_t o = row_base(nt, ck);
+            rg[k] = o != 0xFFFFFFFFu ? *(const uint4*)(resg + o + ck.goff) : make_uint4(0, 0, 0, 0);
+          }
+        }
+        if (SPLIT == 2) {
+#pragma unroll
+          for (int w = 0; w < LW; ++w) lw[w] = log[((size_t)nt * 64 + lane) * LW + w];
+        }
+      };
+      fetch(0);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        __builtin_amdgcn_sched_barrier(0);   // one position tile at a time: interleaving tiles costs registers that are not there
+        uint2 sk[MTW];
+        uint32_t lwc[LW];
+#pragma unroll
+        for (int w = 0; w < LW; ++w) lwc[w] = SPLIT == 2 ? lw[w] : 0u;
+        if (res) {
+#pragma unroll
+          for (int k = 0; k < NK; ++k) { const Chunk ck = chunk(k); if (ck.row != 0xFFu) *(uint4*)(stg + ck.soff) = rg[k]; }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) sk[mt] = *(const uint2*)(stg + r16 * ROWB + mt * 32 + q * 8);
+          __builtin_amdgcn_wave_barrier();
+        }
+        uint32_t lwo[LW];
+#pragma unroll
+        for (int w = 0; w < LW; ++w) lwo[w] = 0u;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+          if (res) {
+            uint32_t sb[4] = {sk[mt].x << 16, sk[mt].x & 0xFFFF0000u, sk[mt].y << 16, sk[mt].y & 0xFFFF0000u};
+            if (SPLIT == 2) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sb[r] += (uint32_t)__builtin_amdgcn_sbfe((int)lwc[mt >> 1], ((mt & 1) * 4 + r) * 4, 4) << 12;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += __uint_as_float(sb[r]);
+          }
+          if (relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_relu(v[r], slope);
+          }
+          uint2 o;
+          if (SPLIT) {
+            uint32_t t[4], h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              t[r] = __float_as_uint(v[r]) + 0x800u;
+              h[r] = (t[r] & 0xFFFFF000u) + 0x8000u;
+              lwo[mt >> 1] |= ((t[r] >> 12) & 0xFu) << (((mt & 1) * 4 + r) * 4);
+            }
+            o.x = (h[0] >> 16) | (h[1] & 0xFFFF0000u);
+            o.y = (h[2] >> 16) | (h[3] & 0xFFFF0000u);
+          } else {
+            o.x = pack_bf16(v[0], v[1]);
+            o.y = pack_bf16(v[2], v[3]);
+          }
+          *(uint2*)(stg + r16 * ROWB + mt * 32 + q * 8) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the next tile's skip words are requested before this tile's stores (vmcnt retires in order)
+        __builtin_amdgcn_sched_barrier(0);
+        if (nt + 1 < NTW) fetch(nt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const Chunk ck = chunk(k);
+          const uint32_t o = row_base(nt, ck);
+          if (o != 0xFFFFFFFFu) *(uint4*)(outg + o + ck.goff) = *(const uint4*)(stg + ck.soff);
+        }
+        if (SPLIT) {
+#pragma unroll
+          for (int w = 0; w < LW; ++w) log[((size_t)nt * 64 + lane) * LW + w] = lwo[w];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+    bool live[NTW];
+    uint32_t obase[NTW];
     // SPLIT: the skip stream's four extra mantissa bits.  They are read and written only by this kernel, each
     // lane its own values, so they are stored in register order: the word of unit u (a channel tile x a pair of
     // position tiles = 8 nibbles per lane) of lane l of wave `wave` of board group g sits at
@@ -551,6 +683,7 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
         }
         if (SPLIT) log[u * 64 + lane] = lwo;
       }
+    }
     }
     CP_SEG(6);   // epilogue
   }
