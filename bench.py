@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--boards", type=int, default=BOARDS_PER_GPU)
     ap.add_argument("--plies", type=int, default=PLIES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (checkers search, checkers-family playouts)")
     ap.add_argument("--no-nn-rollouts", action="store_true", help="skip the configs[3] leg (NN-evaluated MCTS rollouts/s)")
     ap.add_argument("--nn-games", type=int, default=4096)
     ap.add_argument("--nn-moves", type=int, default=1, help="whole 1,600-rollout moves timed by the configs[3] leg")
@@ -306,6 +307,25 @@ def main():
         else:   # the headline line is still printed, the process then exits non-zero
             nn = {"metric": "go_nn_evaluated_mcts_rollouts_per_sec", "value": None, "error": state["err"]}
             nn_failed = True
+    # the reference's own games on the same run (rank 0, one GPU): BASELINE.json configs[2] (checkers search) and the
+    # checkers-family playouts - secondary figures, under "extras"
+    extras = None
+    if rank == 0 and not args.no_extras:
+        try:
+            import gc
+            import importlib.util
+            leg = r = gath = None
+            gc.collect()
+            torch.cuda.empty_cache()
+
+            def load(name):
+                spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "benchmarks", name + ".py"))
+                m = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(m)
+                return m
+            extras = {"checkers_mcts": load("bench_mcts").measure(moves=8), "boards": load("bench_boards").measure(steps=10)}
+        except Exception as e:
+            extras = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         moves_per_launch = moves / max(1, args.steps)
         achieved = ALGO_BYTES_PER_MOVE * moves_per_launch / (kern_ms * 1e-3) / 1e9
@@ -332,6 +352,8 @@ def main():
         }
         if nn is not None:
             out["nn_rollouts"] = nn
+        if extras is not None:
+            out["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -69,16 +69,13 @@ def cpu_reference(threads=16, boards=256, plies=4096):
             "sample": "%d threads x %d boards x %d plies through the compiled reference GameBoard.cc, %.1f s" % (threads, boards, plies, dt)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--boards", type=int, default=65536)
-    ap.add_argument("--plies", type=int, default=64)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu", action="store_true")
-    a = ap.parse_args()
+def measure(boards=65536, plies=64, steps=20, warmup=3, no_cpu=True):
+    """one dict per game (bench.py calls this, GPU half only, for the driver line's `extras`)"""
+    import types
+    a = types.SimpleNamespace(boards=boards, plies=plies, steps=steps, warmup=warmup, no_cpu=no_cpu)
     import torch
     from elf_amd.boards import BoardBatch
+    outs = []
     for name, gid, bytes_per_move, words, prefix in GAMES:
         bb = BoardBatch(gid, a.boards)
         counter = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -110,8 +107,21 @@ def main():
                 if ref is not None:
                     out["cpu_baseline_port"] = out["cpu_baseline"]
                     out["cpu_baseline"] = ref
-        print(json.dumps(out), flush=True)
+        outs.append(out)
         bb.close()
+    return outs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--boards", type=int, default=65536)
+    ap.add_argument("--plies", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+    for out in measure(a.boards, a.plies, a.steps, a.warmup, a.no_cpu):
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

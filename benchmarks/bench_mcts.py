@@ -38,14 +38,10 @@ def cpu_baseline(threads=16, games_per_thread=64, moves=40, batch=8):
                       % (threads, games_per_thread, moves, dt)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--games", type=int, default=16384)
-    ap.add_argument("--moves", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
+def measure(games=16384, moves=12, warmup=2, batch=8):
+    """the GPU half: one JSON-able dict (bench.py also calls this for the driver line's `extras`)"""
+    import types
+    a = types.SimpleNamespace(games=games, moves=moves, warmup=warmup, batch=batch)
     import torch
     from elf_amd.boards import BoardBatch, AMERICAN
     from elf_amd.mcts import TreeSearchBatch
@@ -94,6 +90,18 @@ def main():
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                         "traffic": None, "kernel": "mcts_search_kernel<0>", "kernel_ms": kern_ms,
                         "mean_depth": D, "mean_branching": b, "algorithmic_bytes_per_rollout": bytes_per_rollout}}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--games", type=int, default=16384)
+    ap.add_argument("--moves", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    out = measure(a.games, a.moves, a.warmup, a.batch)
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(batch=a.batch)
     print(json.dumps(out), flush=True)
