@@ -3,6 +3,8 @@ sys.path.insert(0, os.getcwd())
 import torch
 from elf_amd.boards import BoardBatch, GO19
 from elf_amd import _lib
+if os.environ.get("ELFHIP_PROF_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["ELFHIP_PROF_LIB"])
 L = _lib.lib()
 bb = BoardBatch(GO19, 65536)
 out = (C.c_ulonglong * 32)()

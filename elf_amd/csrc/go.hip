@@ -116,11 +116,33 @@ __global__ void __launch_bounds__(64) go_step_kernel(GoDev d, const uint64_t* __
   if (valid && ok) ok[b] = good ? 1 : 0;
 }
 
+// x mod n for n <= 361 with rc = floor((2^32 - 1) / n): the estimate q = mulhi(x, rc) is the quotient or one less
+__device__ inline uint32_t mod_small(uint32_t x, uint32_t n, uint32_t rc) {
+  const uint32_t r = x - __umulhi(x, rc) * n;
+  return r >= n ? r - n : r;
+}
+// position of the k-th (from 0) set bit of a 19-bit row, k < popcount(x): five halving steps, no loop
+__device__ inline uint32_t kth_bit(uint32_t x, int k) {
+  uint32_t pos = 0;
+#pragma unroll
+  for (int w = 16; w >= 1; w >>= 1) {
+    const int c = __popc(x & ((1u << w) - 1u));
+    const bool hi = k >= c;
+    k -= hi ? c : 0; x = hi ? x >> w : x; pos += hi ? (uint32_t)w : 0u;
+  }
+  return pos;
+}
+
 // Random-legal playouts: nply steps per launch with the board in registers.
 __global__ void __launch_bounds__(64)
 go_playout_kernel(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t seed, uint64_t first_id,
                   uint64_t step_base, unsigned long long* __restrict__ moves_out) {
   __shared__ uint64_t z[GO_ZWORDS];
+  __shared__ uint32_t s_mod[2][GO_POINTS + 1];   // per legal-move count n: floor((2^32 - 1) / n), 2^32 mod n
+  for (int n = threadIdx.x + 1; n <= GO_POINTS; n += blockDim.x) {
+    s_mod[0][n] = 0xFFFFFFFFu / (uint32_t)n;
+    s_mod[1][n] = ((0xFFFFFFFFu % (uint32_t)n) + 1u) % (uint32_t)n;
+  }
   go_load_zobrist(z, gz);
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = b < d.n;
@@ -148,8 +170,11 @@ go_playout_kernel(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t s
     int n = go_legal_rows(s, L);
     uint32_t a = GO_PASS;
     if (act && n > 0) {
-      uint64_t r = elf_splitmix64(key + (uint64_t)step);
-      int k = (int)elf_mod_u64_small(r, (uint32_t)n);
+      const uint64_t r = elf_splitmix64(key + (uint64_t)step);
+      // r mod n (= elf_mod_u64_small) through the per-n reciprocals in LDS: three multiply-high reductions
+      const uint32_t rc = s_mod[0][n], p32 = s_mod[1][n];
+      const uint32_t hi = mod_small((uint32_t)(r >> 32), (uint32_t)n, rc), lo = mod_small((uint32_t)r, (uint32_t)n, rc);
+      int k = (int)mod_small(hi * p32 + lo, (uint32_t)n, rc);
       uint32_t row = 0, rowbits = 0;
       bool found = false;
       ROWS(i) {
@@ -158,8 +183,7 @@ go_playout_kernel(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t s
         if (here) { row = i; rowbits = L[i]; found = true; }
         if (!found) k -= c;
       }
-      for (int j = 0; j < k; ++j) rowbits &= rowbits - 1;
-      a = row * 19 + (uint32_t)(__ffs(rowbits) - 1);
+      a = row * 19 + kth_bit(rowbits, k);
     }
     PROF_ADD(4);
     go_forward(s, act, a, tab, gen, z);

@@ -124,44 +124,51 @@ __device__ inline int go_legal_rows(const GoS& s, uint32_t (&L)[GN]) {
   return n;
 }
 
-// One growth pass over the whole board, in place: rows in ascending (DOWN) or descending order, each
-// row taking its already-updated predecessor, so the set spreads all the way along the sweep
-// direction, one row against it and two points sideways.
-//   inc  = bits that were added (0 <=> F was already a union of complete M-components)
-//   nlib = distinct empty points adjacent to the stones the pass looked at: a lower bound of the
-//          group's liberties, exact when inc == 0 (E = empty points)
-// ~15 VALU instructions per row; the evaluation rides on the neighbourhood the growth needs anyway.
+// One growth pass over the whole board, in place: rows in ascending (DOWN) or descending order.  A row takes the
+// final value of its predecessor in sweep order and is then flooded EXACTLY along the row: for a seed set x inside a
+// row mask m, (m + x) carries through every run of m upwards from its lowest seed, so ((m + x) ^ m) & m are the run
+// bits above the seeds; the same on the bit-reversed row gives the bits below.  After the pass every row is closed
+// sideways and towards the sweep direction; what can be left open is only the direction the sweep came from:
+//   pend = bits whose neighbour in the row before (in sweep order) is an M point the set does not hold.
+// pend == 0 <=> F is a union of complete M-components: no extra pass is needed to prove the fixpoint.
+//   nlib = distinct empty points (E) adjacent to F as the pass leaves it (each row is counted one step later,
+//          when both of its vertical neighbours are final): a lower bound of the group's liberties, exact when pend == 0.
+// ~16 VALU instructions per row.
 template <bool EVAL, bool DOWN>
-__device__ inline void go_grow(uint32_t (&F)[GN], const uint32_t (&M)[GN], const uint32_t (&E)[GN], uint32_t& inc, int& nlib) {
-  inc = 0; nlib = 0;
-  uint32_t prev = 0;  // the row before this one in sweep order, after its update
+__device__ inline void go_grow(uint32_t (&F)[GN], const uint32_t (&M)[GN], const uint32_t (&E)[GN], uint32_t& pend, int& nlib) {
+  pend = 0; nlib = 0;
+  uint32_t prev = 0, prev2 = 0;  // the rows one and two steps back in sweep order, final
 #pragma unroll
   for (int k = 0; k < GN; ++k) {
     const int i = DOWN ? k : GN - 1 - k;
-    const int j = DOWN ? i + 1 : i - 1;                       // the row after this one: not updated yet
-    const uint32_t f = F[i];
-    const uint32_t nx = (j >= 0 && j < GN) ? F[(j >= 0 && j < GN) ? j : 0] : 0u;
-    const uint32_t nb = (f << 1) | (f >> 1) | prev | nx;
-    uint32_t g = nb & M[i];
-    g = (g | (g << 1) | (g >> 1)) & M[i];
-    inc |= g & ~f;
-    if (EVAL) nlib += __popc(nb & E[i]);
-    prev = f | g;
-    F[i] = prev;
+    const int ip = k > 0 ? (DOWN ? i - 1 : i + 1) : i;       // the row before this one in sweep order
+    const uint32_t m = M[i];
+    const uint32_t x = F[i] | (prev & m);
+    const uint32_t up = ((m + x) ^ m) & m;
+    const uint32_t mr = __brev(m), xr = __brev(x);
+    const uint32_t dn = ((mr + xr) ^ mr) & mr;
+    const uint32_t g = x | up | __brev(dn);
+    F[i] = g;
+    if (k > 0) {
+      pend |= g & M[ip] & ~prev;
+      if (EVAL) nlib += __popc(((prev << 1) | (prev >> 1) | prev2 | g) & E[ip]);
+    }
+    prev2 = prev; prev = g;
   }
+  if (EVAL) nlib += __popc(((prev << 1) | (prev >> 1) | prev2) & E[DOWN ? GN - 1 : 0]);
 }
 
 // grow F (subset of M) to the complete M-components it touches; every lane of the wave takes part
 __device__ inline void go_fill_complete(uint32_t (&F)[GN], const uint32_t (&M)[GN]) {
   PROF_INC(20, 1);
   for (;;) {
-    uint32_t inc; int nl;
+    uint32_t pend; int nl;
     PROF_INC(21, 1);
-    go_grow<false, true>(F, M, M, inc, nl);
-    if (!__any(inc != 0)) break;
+    go_grow<false, true>(F, M, M, pend, nl);
+    if (!__any(pend != 0)) break;
     PROF_INC(21, 1);
-    go_grow<false, false>(F, M, M, inc, nl);
-    if (!__any(inc != 0)) break;
+    go_grow<false, false>(F, M, M, pend, nl);
+    if (!__any(pend != 0)) break;
   }
 }
 
@@ -178,23 +185,23 @@ __device__ inline void go_group_status(GoS& s, uint32_t (&F)[GN], const uint32_t
   int nlib = 0;
   PROF_INC(20, 1);
   for (;;) {
-    uint32_t inc;
+    uint32_t pend;
     PROF_INC(21, 1);
-    go_grow<true, true>(F, M, E, inc, nlib);
+    go_grow<true, true>(F, M, E, pend, nlib);
     if (!fin) {
-      if (inc == 0) fin = true;
+      if (pend == 0) fin = true;
       else if (nlib >= 2 && !need_full) { fin = true; noop = true; }
     }
     if (!__any(!fin)) break;
     PROF_INC(21, 1);
-    go_grow<true, false>(F, M, E, inc, nlib);
+    go_grow<true, false>(F, M, E, pend, nlib);
     if (!fin) {
-      if (inc == 0) fin = true;
+      if (pend == 0) fin = true;
       else if (nlib >= 2 && !need_full) { fin = true; noop = true; }
     }
     if (!__any(!fin)) break;
   }
-  // a finished-by-completion lane re-evaluates the same complete F on later passes: nlib stays exact
+  // a lane that finished by completion re-evaluates the same complete F on later passes: nlib stays exact
   size = 0;
   if (!noop) {
     const bool in_atari = nlib == 1;

@@ -211,6 +211,12 @@ __device__ inline void lds_dma16(const char* gsrc, const char* lds_dst) {
   const uint32_t l = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst;
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory", "m0");
 }
+// the same with a wave-uniform base (scalar register pair) and a 32-bit per-lane byte offset: no 64-bit address
+// is formed in vector registers (one vector add and two registers less per piece)
+__device__ inline void lds_dma16s(const char* sbase, uint32_t voff, const char* lds_dst) {
+  const uint32_t l = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(l) : "memory", "m0");
+}
 
 // Board-tiled 3x3 convolution (the fast path for 19x19 and 8x8): one 512-thread workgroup owns NBW
 // whole boards.  For every 32-channel input chunk the padded activations of those boards are staged
@@ -316,8 +322,13 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
       const uint32_t ch = slot - row * 5u;
       row = min(row, (uint32_t)(rows_left - 1));
       const uint32_t off = (row * CIN + (ch == 4 ? 0 : ch) * 8) * 2u;
-      if (j < XI)
+      if (j < XI) {
+#ifdef CONV_SADDR
+        lds_dma16s(src, off, sX + buf * XBYTES + j * 1024);
+#else
         lds_dma16(src + off, sX + buf * XBYTES + j * 1024);
+#endif
+      }
     }
   };
   auto dma_a = [&](int tap, int c0, int buf) {
@@ -327,8 +338,13 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
 #pragma unroll
     for (int i = 0; i < NAW; ++i) {
       const int j = apiece(i);
-      if (j < AI)
+      if (j < AI) {
+#ifdef CONV_SADDR
+        lds_dma16s(src, aoff[i], sA + buf * ABYTES + j * 1024);
+#else
         lds_dma16(src + aoff[i], sA + buf * ABYTES + j * 1024);
+#endif
+      }
     }
   };
 
@@ -355,7 +371,7 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
 
   f32x4 acc[MTW][NTW];
   // one stage = one tap x 32 input channels: MTW x NTW MFMAs per wave
-  auto compute = [&](int tap, int slot, int xbuf) {
+  auto compute = [&](int tap, int slot, int xbuf, auto&& gap) {
     const int ty = tap / 3;
     const char* A = Alane + slot * ABYTES;
     const char* X = sX + xbuf * XBYTES + (ty * PW + (tap - ty * 3)) * 80;
@@ -378,8 +394,10 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, MTW, 0);
+      gap(nt);
     }
   };
+  auto no_gap = [](int) {};
 
   CP_DECL;
   int G = 0;        // global stage index of the pair being computed
@@ -419,20 +437,89 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
           else if (bi + 1 < nmine) { dma_x(g + (int)gridDim.x, 0, (gchunk0 + 1) & 1); inflight += nX; }
         }
       };
+#ifdef CONV_GAP_DMA
+      {
+        // Pieces in the gaps: the pair's DMA pieces are issued one at a time between the position-tile groups of
+        // MFMAs (the matrix pipe keeps running on what was already issued; a burst of pieces at one point of the
+        // pair stops the wave's MFMA stream for as long as the burst takes to issue).  What is requested is
+        // decided here from the state at the top of the pair, as scalars; gap p issues piece p of the list
+        //   [slice 0: NAW pieces][slice 1: NAW pieces][activation chunk: NXW pieces]
+        const char* srcA[2] = {nullptr, nullptr}; int ldsA[2] = {0, 0}; bool cA[2] = {false, false};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          cA[k] = issued < G0 + 6 && issued < total;
+          if (cA[k]) {
+            srcA[k] = (const char*)(w + ((size_t)it_tap * (CIN / KC) + it_chunk) * COUT * KC);
+            ldsA[k] = it_slot * ABYTES;
+            ++issued;
+            it_slot = it_slot + 1 == RING ? 0 : it_slot + 1;
+            if (++it_tap == 9) { it_tap = 0; if (++it_chunk == nchunk) it_chunk = 0; }
+            inflight += nA;
+          }
+        }
+        bool cX = false; int xg = 0, xc0 = 0;
+        if (tap0 == 3 || tap0 == 4) {
+          if (chunk0 + 1 < nchunk) { cX = true; xg = g; xc0 = (chunk0 + 1) * KC; }
+          else if (bi + 1 < nmine) { cX = true; xg = g + (int)gridDim.x; xc0 = 0; }
+          if (cX) inflight += nX;
+        }
+        const long xr0 = (long)xg * XROWS;
+        const int xrows_left = (int)min((long)XROWS, (long)B * PP - xr0);
+        const char* xsrc = (const char*)(x + xr0 * CIN) + xc0 * 2;
+        char* const xdst = sX + ((gchunk0 + 1) & 1) * XBYTES;
+        auto piece = [&](int p) {
+          if (p < 2 * NAW) {
+            const int k = p / NAW, i = p - k * NAW;
+            const int j = apiece(i);
+            if (cA[k] && j < AI) lds_dma16s(srcA[k], aoff[i], sA + ldsA[k] + j * 1024);
+          } else if (p < 2 * NAW + NXW) {
+            const int i = p - 2 * NAW;
+            const int j = wave + 8 * i;
+            if (cX && j < XI) {
+              uint32_t slot = (uint32_t)(wave * 64 + lane) + 512u * i;
+              asm volatile("" : "+v"(slot));
+              uint32_t row = slot / 5u;
+              const uint32_t ch = slot - row * 5u;
+              row = min(row, (uint32_t)(xrows_left - 1));
+              lds_dma16s(xsrc, (row * CIN + (ch == 4 ? 0 : ch) * 8) * 2u, xdst + j * 1024);
+            }
+          }
+        };
+        // more pieces than gaps (not the case for the shapes in use): the rest at the top
+#pragma unroll
+        for (int p = 2 * NTW; p < 2 * NAW + NXW; ++p) piece(p);
+        CP_SEG(0);
+        compute(tap, gslot, gchunk & 1, [&](int nt) { piece(nt); });
+        CP_SEG(1);
+        ++G; gslot = gslot + 1 == RING ? 0 : gslot + 1;
+        if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
+        CP_SEG(3);
+        if (s + 1 < nstage) {
+          compute(tap, gslot, gchunk & 1, [&](int nt) { piece(NTW + nt); });
+          ++G; gslot = gslot + 1 == RING ? 0 : gslot + 1;
+          if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
+        } else {
+#pragma unroll
+          for (int p = NTW; p < 2 * NTW; ++p) piece(p);
+        }
+        CP_SEG(2);
+      }
+#else
       if (!late) request();
       CP_SEG(0);
-      compute(tap, gslot, gchunk & 1);
+      compute(tap, gslot, gchunk & 1, no_gap);
       CP_SEG(1);
       ++G; gslot = gslot + 1 == RING ? 0 : gslot + 1;
       if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
       if (late) request();   // between its two stages: the partner wave is in the middle of its MFMAs by now
       CP_SEG(3);
       if (s + 1 < nstage) {
-        compute(tap, gslot, gchunk & 1);
+        compute(tap, gslot, gchunk & 1, no_gap);
         ++G; gslot = gslot + 1 == RING ? 0 : gslot + 1;
         if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
       }
       CP_SEG(2);
+#endif
       wait_vmcnt(inflight);
       CP_SEG(4);
       __builtin_amdgcn_s_barrier();

@@ -1,0 +1,64 @@
+"""Generate tests/golden/net_ref_*.npz by running the REFERENCE's own model code
+(/root/reference/src_py/elfgames/american_checkers/model_american_checkers.py: Model_PolicyValue, imported, not
+restated) on the inputs of the net_*.npz fixtures, with the same seeded weights loaded through load_state_dict
+(strict: the key names and shapes of oracle/model_ref.py are the reference's).  This is what pins the network oracle:
+tests/test_model_ref_pinned.py checks oracle/model_ref.py against these outputs, tests/test_gpu_net.py checks the HIP
+network against them.
+
+Runs in the build container only (the reference never travels).  Its `elf` package loads the facade `_elf` built in
+elf_amd/pybind; `pyzmq` is absent from the image, so an empty module named zmq is put into sys.modules first, as in
+tests/test_reference_python_drop_in.py.  Run from anywhere:
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_net_reference.py
+"""
+import glob
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path[:0] = [os.path.join(REF, "src_py"), os.path.join(REF, "scripts", "elfgames", "american_checkers", "py"),
+                os.path.join(ROOT, "elf_amd", "pybind"), ROOT]
+sys.modules.setdefault("zmq", types.ModuleType("zmq"))
+
+from oracle.model_ref import seeded_model  # noqa: E402  (weights only: the state_dict that is loaded into the reference model)
+import elfgames.american_checkers.model_american_checkers as refmodel  # noqa: E402
+
+
+def main():
+    torch.set_num_threads(8)
+    only = sys.argv[1:]
+    for path in sorted(glob.glob(os.path.join(HERE, "net_*.npz"))):
+        name = os.path.basename(path)[4:-4]
+        if name.startswith("ref_") or (only and name not in only):
+            continue
+        g = np.load(path)
+        planes, board, dim, num_block, num_action = (int(v) for v in g["cfg"])
+        leaky, seed = ("leaky" in g.files and bool(int(g["leaky"]))), int(g["seed"])
+        shape = tuple(int(v) for v in g["x_shape"])
+        x = np.unpackbits(g["x"])[: int(np.prod(shape))].reshape(shape).astype(np.float32)
+        args = ["--dim", str(dim), "--num_block", str(num_block)] + (["--leaky_relu"] if leaky else [])
+        om = refmodel.Model_PolicyValue.get_option_spec().parse(args=args)
+        params = {"checkers_num_action": num_action, "checkers_board_size": board, "checkers_num_future_actions": 1,
+                  "checkers_num_planes": planes}
+        model = refmodel.Model_PolicyValue(om, params)
+        sd = seeded_model(seed=seed, planes=planes, board=board, dim=dim, num_block=num_block, num_action=num_action,
+                          leaky_relu=leaky).state_dict()
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        with torch.no_grad():
+            o = model(dict(s=torch.from_numpy(x)))
+        np.savez_compressed(os.path.join(HERE, "net_ref_%s.npz" % name), pi=o["pi"].numpy(), logpi=o["logpi"].numpy(), V=o["V"].numpy(),
+                            meta=np.array(["reference Model_PolicyValue (model_american_checkers.py) on torch %s CPU fp32, eval mode; "
+                                           "inputs and weight seed of net_%s.npz" % (torch.__version__, name)]))
+        print(name, "pi max", float(o["pi"].max()), "V absmax", float(o["V"].abs().max()),
+              "| vs net_%s.npz: dpi %.3g dV %.3g" % (name, float(np.abs(o["pi"].numpy() - g["pi"]).max()), float(np.abs(o["V"].numpy() - g["V"]).max())))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,43 @@
+"""oracle/model_ref.py (the network oracle) against the outputs of the reference's own model code.
+
+tests/golden/net_ref_*.npz hold pi / logpi / V of `Model_PolicyValue` from
+/root/reference/src_py/elfgames/american_checkers/model_american_checkers.py - imported and run, not restated, by
+tests/golden/gen_net_reference.py in the build container - on the inputs of the net_*.npz fixtures with the same
+seeded weights loaded through load_state_dict(strict=True).  The restatement must reproduce them (same torch ops in
+the same order: equal to the last bit on the torch build that made them; 1e-6 leaves room for another build's
+kernels), for ReLU and --leaky_relu models, 8x8 and 19x19, up to the 20-block x 224 network of configs[3]."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.model_ref import seeded_model
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = sorted(os.path.basename(p)[8:-4] for p in glob.glob(os.path.join(GOLD, "net_ref_*.npz")))
+
+
+def test_every_network_fixture_has_reference_outputs():
+    plain = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLD, "net_*.npz")) if not os.path.basename(p).startswith("net_ref_"))
+    assert plain == NAMES and len(NAMES) >= 7
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_restatement_reproduces_the_reference_model(name):
+    g = np.load(os.path.join(GOLD, "net_%s.npz" % name))
+    r = np.load(os.path.join(GOLD, "net_ref_%s.npz" % name))
+    planes, board, dim, num_block, num_action = (int(v) for v in g["cfg"])
+    leaky = "leaky" in g.files and bool(int(g["leaky"]))
+    shape = tuple(int(v) for v in g["x_shape"])
+    x = np.unpackbits(g["x"])[: int(np.prod(shape))].reshape(shape).astype(np.float32)
+    torch.set_num_threads(8)
+    m = seeded_model(seed=int(g["seed"]), planes=planes, board=board, dim=dim, num_block=num_block, num_action=num_action, leaky_relu=leaky)
+    with torch.no_grad():
+        o = m(torch.from_numpy(x))
+    assert np.abs(o["pi"].numpy() - r["pi"]).max() <= 1e-6
+    assert np.abs(o["V"].numpy() - r["V"]).max() <= 1e-6
+    # and the committed restatement fixture is the same data
+    assert np.abs(g["pi"] - r["pi"]).max() <= 1e-6 and np.abs(g["V"] - r["V"]).max() <= 1e-6
+    assert r["pi"].shape == (shape[0], num_action) and np.abs(np.exp(r["logpi"]) - r["pi"]).max() <= 1e-6
