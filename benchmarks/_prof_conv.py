@@ -5,6 +5,8 @@ sys.path.insert(0, os.getcwd())
 import torch
 from elf_amd.net import PolicyValueNet, random_state_dict
 from elf_amd import _lib
+if os.environ.get("ELFHIP_PROF_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["ELFHIP_PROF_LIB"])
 L = _lib.lib()
 cfg = dict(planes=18, board=19, dim=224, num_block=20, num_action=362)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

@@ -48,14 +48,16 @@ constexpr int LROW = 40;      // LDS row stride in bf16 (32 data + 8 pad = 80 B)
 constexpr int BP = 128;       // positions per workgroup
 
 // "s" [B][C][H][W] f32  ->  padded NHWC bf16 [B][H+2][W+2][CP] (interior only; borders pre-zeroed)
-__global__ void net_pack_input_kernel(const float* __restrict__ s, uint16_t* __restrict__ x, int B, int C, int H, int W, int CP) {
+// CS = 0: NHWC as above; CS > 0: the board kernel's chunk-major layout (see conv3x3_board_kernel), CS rows per chunk plane
+__global__ void net_pack_input_kernel(const float* __restrict__ s, uint16_t* __restrict__ x, int B, int C, int H, int W, int CP, long CS) {
   const size_t total = (size_t)B * H * W * CP;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     int c = (int)(i % CP); size_t p = i / CP;
     int xw = (int)(p % W); p /= W;
     int y = (int)(p % H); int n = (int)(p / H);
     float v = c < C ? s[(((size_t)n * C + c) * H + y) * W + xw] : 0.f;
-    x[(((size_t)n * (H + 2) + y + 1) * (W + 2) + xw + 1) * CP + c] = f2bf(v);
+    const size_t row = ((size_t)n * (H + 2) + y + 1) * (W + 2) + xw + 1;
+    x[CS ? ((size_t)(c >> 5) * CS + row) * 32 + (c & 31) : row * CP + c] = f2bf(v);
   }
 }
 
@@ -211,13 +213,6 @@ __device__ inline void lds_dma16(const char* gsrc, const char* lds_dst) {
   const uint32_t l = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst;
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory", "m0");
 }
-// the same with a wave-uniform base (scalar register pair) and a 32-bit per-lane byte offset: no 64-bit address
-// is formed in vector registers (one vector add and two registers less per piece)
-__device__ inline void lds_dma16s(const char* sbase, uint32_t voff, const char* lds_dst) {
-  const uint32_t l = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst;
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(l) : "memory", "m0");
-}
-
 // Board-tiled 3x3 convolution (the fast path for 19x19 and 8x8): one 512-thread workgroup owns NBW
 // whole boards.  For every 32-channel input chunk the padded activations of those boards are staged
 // in LDS ONCE and serve all nine taps, so HBM/L2 sees each activation once per layer instead of
@@ -241,6 +236,12 @@ __device__ inline void lds_dma16s(const char* sbase, uint32_t voff, const char* 
 // fragments are read two position tiles ahead of the MFMAs that consume them.
 // Wave grid 2 (output-channel halves) x 4 (position quarters); a wave keeps COUT/32 x NTW
 // accumulator tiles (16x16 fp32) in registers, so each LDS fragment read feeds 6-7 MFMAs.
+// Activation layout (x, res, out): CHUNK-MAJOR, [channel / 32][padded row of the whole batch][channel % 32] with CS
+// rows per chunk plane (CS = max_batch x (H+2)^2, fixed per network, so the zero borders stay where they are): the 64
+// bytes of one padded position and one 32-channel chunk are contiguous and consecutive positions follow each other.
+// The staging DMA of a chunk reads one contiguous run, and - what pays - the epilogue writes whole 64-byte rows of
+// 16 consecutive positions per wave instruction (1 KiB runs) instead of 32-byte pieces 2 x COUT bytes apart: the
+// stores were 23 % of the Go forward with the NHWC layout (timing experiments in profiles/r02_conv_segments.md).
 // SPLIT: 0 = plain bf16 output; 1 = also write the four extra mantissa bits of the output to `lo` (the stem);
 // 2 = the skip value read is res extended by its nibble in `lo`, and the output is split again, lo updated in
 // place (conv_upper) - see NetImpl::lo.
@@ -248,7 +249,7 @@ template <int COUT, int H, int NBW, int SPLIT>
 __global__ void __launch_bounds__(512)
 conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
                      const uint16_t* __restrict__ res, uint16_t* __restrict__ out, uint16_t* lo, int B, int CIN, int relu, float slope,
-                     int late_half, int stagger, int phases) {
+                     int late_half, int stagger, int phases, long CS) {
   constexpr int PW = H + 2, PP = PW * PW, HW = H * H;
   constexpr int PT = NBW * HW;             // output positions of this workgroup
   constexpr int NT = (PT + 15) / 16;       // position tiles
@@ -311,7 +312,7 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
   auto dma_x = [&](int g, int c0, int buf) {
     const long xrow0 = (long)g * XROWS;
     const int rows_left = (int)min((long)XROWS, (long)B * PP - xrow0);
-    const char* src = (const char*)(x + xrow0 * CIN) + c0 * 2;
+    const char* src = (const char*)(x + ((size_t)(c0 / KC) * CS + xrow0) * KC);   // the chunk's plane: 64-byte rows
     uint32_t slot0 = (uint32_t)(wave * 64 + lane);
     asm volatile("" : "+v"(slot0));
 #pragma unroll
@@ -321,14 +322,9 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
       uint32_t row = slot / 5u;
       const uint32_t ch = slot - row * 5u;
       row = min(row, (uint32_t)(rows_left - 1));
-      const uint32_t off = (row * CIN + (ch == 4 ? 0 : ch) * 8) * 2u;
-      if (j < XI) {
-#ifdef CONV_SADDR
-        lds_dma16s(src, off, sX + buf * XBYTES + j * 1024);
-#else
+      const uint32_t off = (row * KC + (ch == 4 ? 0 : ch) * 8) * 2u;
+      if (j < XI)
         lds_dma16(src + off, sX + buf * XBYTES + j * 1024);
-#endif
-      }
     }
   };
   auto dma_a = [&](int tap, int c0, int buf) {
@@ -338,13 +334,8 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
 #pragma unroll
     for (int i = 0; i < NAW; ++i) {
       const int j = apiece(i);
-      if (j < AI) {
-#ifdef CONV_SADDR
-        lds_dma16s(src, aoff[i], sA + buf * ABYTES + j * 1024);
-#else
+      if (j < AI)
         lds_dma16(src + aoff[i], sA + buf * ABYTES + j * 1024);
-#endif
-      }
     }
   };
 
@@ -367,17 +358,22 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
   for (int s2 = 0; s2 < 4 && s2 < total; ++s2) issue_next();
   wait_vmcnt(total > 2 ? 2 * nA : 0);   // stages 0,1 (and the first chunk) have landed; 2,3 may still fly
   __syncthreads();
-  const char* Alane = sA + wc * MTW * 1024 + q * 256 + r16 * 16;
+  // Output-channel tiles of a wave: tile_of(mt).  With an odd number of tiles per wave the first MTW - 1 of each wave
+  // are whole 32-channel chunks (pairs of tiles) and the two waves share the last chunk (tile 2 (MTW - 1) + wc), so
+  // that both waves run the same epilogue: pairs of tiles write whole 64-byte rows.
+  auto tile_of = [&](int mt) { return (MTW & 1) && mt == MTW - 1 ? 2 * (MTW - 1) + wc : wc * ((MTW & 1) ? MTW - 1 : MTW) + mt; };
+  const char* Alane = sA + wc * ((MTW & 1) ? MTW - 1 : MTW) * 1024 + q * 256 + r16 * 16;
+  const int alast = ((2 * (MTW - 1) + wc) - wc * (MTW - 1)) * 1024;   // odd MTW: the last tile's offset from Alane
 
   f32x4 acc[MTW][NTW];
   // one stage = one tap x 32 input channels: MTW x NTW MFMAs per wave
-  auto compute = [&](int tap, int slot, int xbuf, auto&& gap) {
+  auto compute = [&](int tap, int slot, int xbuf) {
     const int ty = tap / 3;
     const char* A = Alane + slot * ABYTES;
     const char* X = sX + xbuf * XBYTES + (ty * PW + (tap - ty * 3)) * 80;
     bf16x8 a[MTW];
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) a[mt] = *(const bf16x8*)(A + mt * 1024);
+    for (int mt = 0; mt < MTW; ++mt) a[mt] = *(const bf16x8*)(A + ((MTW & 1) && mt == MTW - 1 ? alast : mt * 1024));
     bf16x8 bfr[NTW];
     bfr[0] = *(const bf16x8*)(X + pb[0]);
     if (NTW > 1) bfr[1] = *(const bf16x8*)(X + pb[NTW > 1 ? 1 : 0]);
@@ -394,10 +390,8 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, MTW, 0);
-      gap(nt);
     }
   };
-  auto no_gap = [](int) {};
 
   CP_DECL;
   int G = 0;        // global stage index of the pair being computed
@@ -437,89 +431,20 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
           else if (bi + 1 < nmine) { dma_x(g + (int)gridDim.x, 0, (gchunk0 + 1) & 1); inflight += nX; }
         }
       };
-#ifdef CONV_GAP_DMA
-      {
-        // Pieces in the gaps: the pair's DMA pieces are issued one at a time between the position-tile groups of
-        // MFMAs (the matrix pipe keeps running on what was already issued; a burst of pieces at one point of the
-        // pair stops the wave's MFMA stream for as long as the burst takes to issue).  What is requested is
-        // decided here from the state at the top of the pair, as scalars; gap p issues piece p of the list
-        //   [slice 0: NAW pieces][slice 1: NAW pieces][activation chunk: NXW pieces]
-        const char* srcA[2] = {nullptr, nullptr}; int ldsA[2] = {0, 0}; bool cA[2] = {false, false};
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          cA[k] = issued < G0 + 6 && issued < total;
-          if (cA[k]) {
-            srcA[k] = (const char*)(w + ((size_t)it_tap * (CIN / KC) + it_chunk) * COUT * KC);
-            ldsA[k] = it_slot * ABYTES;
-            ++issued;
-            it_slot = it_slot + 1 == RING ? 0 : it_slot + 1;
-            if (++it_tap == 9) { it_tap = 0; if (++it_chunk == nchunk) it_chunk = 0; }
-            inflight += nA;
-          }
-        }
-        bool cX = false; int xg = 0, xc0 = 0;
-        if (tap0 == 3 || tap0 == 4) {
-          if (chunk0 + 1 < nchunk) { cX = true; xg = g; xc0 = (chunk0 + 1) * KC; }
-          else if (bi + 1 < nmine) { cX = true; xg = g + (int)gridDim.x; xc0 = 0; }
-          if (cX) inflight += nX;
-        }
-        const long xr0 = (long)xg * XROWS;
-        const int xrows_left = (int)min((long)XROWS, (long)B * PP - xr0);
-        const char* xsrc = (const char*)(x + xr0 * CIN) + xc0 * 2;
-        char* const xdst = sX + ((gchunk0 + 1) & 1) * XBYTES;
-        auto piece = [&](int p) {
-          if (p < 2 * NAW) {
-            const int k = p / NAW, i = p - k * NAW;
-            const int j = apiece(i);
-            if (cA[k] && j < AI) lds_dma16s(srcA[k], aoff[i], sA + ldsA[k] + j * 1024);
-          } else if (p < 2 * NAW + NXW) {
-            const int i = p - 2 * NAW;
-            const int j = wave + 8 * i;
-            if (cX && j < XI) {
-              uint32_t slot = (uint32_t)(wave * 64 + lane) + 512u * i;
-              asm volatile("" : "+v"(slot));
-              uint32_t row = slot / 5u;
-              const uint32_t ch = slot - row * 5u;
-              row = min(row, (uint32_t)(xrows_left - 1));
-              lds_dma16s(xsrc, (row * CIN + (ch == 4 ? 0 : ch) * 8) * 2u, xdst + j * 1024);
-            }
-          }
-        };
-        // more pieces than gaps (not the case for the shapes in use): the rest at the top
-#pragma unroll
-        for (int p = 2 * NTW; p < 2 * NAW + NXW; ++p) piece(p);
-        CP_SEG(0);
-        compute(tap, gslot, gchunk & 1, [&](int nt) { piece(nt); });
-        CP_SEG(1);
-        ++G; gslot = gslot + 1 == RING ? 0 : gslot + 1;
-        if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
-        CP_SEG(3);
-        if (s + 1 < nstage) {
-          compute(tap, gslot, gchunk & 1, [&](int nt) { piece(NTW + nt); });
-          ++G; gslot = gslot + 1 == RING ? 0 : gslot + 1;
-          if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
-        } else {
-#pragma unroll
-          for (int p = NTW; p < 2 * NTW; ++p) piece(p);
-        }
-        CP_SEG(2);
-      }
-#else
       if (!late) request();
       CP_SEG(0);
-      compute(tap, gslot, gchunk & 1, no_gap);
+      compute(tap, gslot, gchunk & 1);
       CP_SEG(1);
       ++G; gslot = gslot + 1 == RING ? 0 : gslot + 1;
       if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
       if (late) request();   // between its two stages: the partner wave is in the middle of its MFMAs by now
       CP_SEG(3);
       if (s + 1 < nstage) {
-        compute(tap, gslot, gchunk & 1, no_gap);
+        compute(tap, gslot, gchunk & 1);
         ++G; gslot = gslot + 1 == RING ? 0 : gslot + 1;
         if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
       }
       CP_SEG(2);
-#endif
       wait_vmcnt(inflight);
       CP_SEG(4);
       __builtin_amdgcn_s_barrier();
@@ -531,8 +456,9 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
     // Output addressing: wave-uniform base pointers of this board group + 32-bit per-lane element
     // offsets, derived here from pb (through an opaque copy: hoisted out of the board loop they would
     // sit in registers - or in scratch - across the whole main loop).
-    const uint16_t* const resg = res ? res + (size_t)xrow0 * COUT : nullptr;
-    uint16_t* const outg = out + (size_t)xrow0 * COUT;
+    // chunk-major: element (row, channel) of this board group at (channel / 32 * CS + xrow0 + row) * 32 + channel % 32
+    const uint16_t* const resg = res ? res + (size_t)xrow0 * 32 : nullptr;
+    uint16_t* const outg = out + (size_t)xrow0 * 32;
     // STAGED epilogue: the accumulator layout gives a lane 4 channels of one position per tile, i.e. 8-byte pieces
     // 32 bytes apart - as global accesses that is 32 lines touched per wave instruction.  Instead each position tile
     // (16 positions x this wave's 16*MTW channels) goes through a private staging area in LDS - the activation buffer
@@ -542,7 +468,7 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
     // Only where the accumulators leave registers for it: the 19x19 x 224 tile keeps 168 of the 256 VGPRs in
     // accumulators and the staging's chunk registers then spill into the main loop (measured: 410 -> 524 ms per
     // 32,768 Go positions), so that shape keeps the direct epilogue below; 8x8 x 128 gains 7 %.
-    constexpr bool STAGED = 8 * 16 * ROWB <= XBYTES && MTW * NTW * 4 <= 96;
+    constexpr bool STAGED = 8 * 16 * ROWB <= XBYTES && MTW * NTW * 4 <= 96 && (MTW == 1 || MTW % 2 == 0);
     if constexpr (STAGED) {
       constexpr int CH = 2 * MTW;                       // 16-byte chunks per staged row
       constexpr int NCH = 16 * CH, NK = (NCH + 63) / 64;
@@ -555,12 +481,12 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
         const int p = (wp * NTW + nt) * 16 + r16;
         uint32_t pbv = (uint32_t)pb[nt];
         asm volatile("" : "+v"(pbv));
-        ob[nt] = (p < PT && board0 + p / HW < B) ? (pbv / 80u + (PW + 1)) * COUT : 0xFFFFFFFFu;
+        ob[nt] = (p < PT && board0 + p / HW < B) ? (pbv / 80u + (PW + 1)) * 32u : 0xFFFFFFFFu;
       }
       // bias first, one channel tile at a time: (acc + bias) + skip, the same float operations as before
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) {
-        const float4 bv = *(const float4*)(bias + (wc * MTW + mt) * 16 + q * 4);
+        const float4 bv = *(const float4*)(bias + tile_of(mt) * 16 + q * 4);
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) { acc[mt][nt][0] += bv.x; acc[mt][nt][1] += bv.y; acc[mt][nt][2] += bv.z; acc[mt][nt][3] += bv.w; }
       }
@@ -573,7 +499,10 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
         asm volatile("" : "+v"(l));
         const uint32_t c = (uint32_t)(k * 64) + l;
         const uint32_t row = c / (uint32_t)CH, col = c - row * (uint32_t)CH;
-        return Chunk{c < (uint32_t)NCH ? row : 0xFFu, row * ROWB + col * 16, (uint32_t)(wc * MTW * 16) + col * 8};
+        // 16-byte column `col` of the staged row = channels ch0 .. ch0 + 7 of this wave's run (the staged shapes have one
+        // tile or an even number of tiles per wave: the run is contiguous): chunk plane ch0 / 32, offset ch0 % 32
+        const uint32_t ch0 = (uint32_t)(wc * MTW * 16) + col * 8;
+        return Chunk{c < (uint32_t)NCH ? row : 0xFFu, row * ROWB + col * 16, (ch0 >> 5) * (uint32_t)(CS * 32) + (ch0 & 31u)};
       };
       auto row_base = [&](int nt, const Chunk& ck) -> uint32_t {   // the offset held by the lane whose position is this chunk's row
         const uint32_t o = (uint32_t)__shfl((int)ob[nt], (int)(ck.row & 15u));
@@ -665,111 +594,146 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
         __builtin_amdgcn_wave_barrier();
       }
     } else {
+    // ---- direct epilogue (accumulators -> bias, skip, activation -> bf16 -> global), chunk-major output ----
+    // Units of two accumulator tiles whose eight words per lane leave as ONE 16-byte store after v_permlane16_swap
+    // (which exchanges the odd 16-lane rows of one register with the even rows of another):
+    //   pair unit   = the two channel tiles of a 32-channel chunk x one position tile: the four lanes of a position
+    //                 then hold the chunk's channels 0-7 / 16-23 / 8-15 / 24-31, i.e. its whole 64-byte row, and the
+    //                 16 positions of the tile are consecutive rows - a wave instruction writes 1 KiB runs;
+    //   single unit = (odd number of tiles per wave) the last tile x a pair of position tiles: 32-byte half rows.
+    // The skip words are read with the same addresses and un-swapped (the swap is its own inverse).
+    constexpr int MP = MTW / 2, NP = (NTW + 1) / 2;
+    constexpr bool ODD = (MTW & 1) != 0;
+    constexpr int NU = MP * NTW + (ODD ? NP : 0);
     bool live[NTW];
-    uint32_t obase[NTW];
-    // SPLIT: the skip stream's four extra mantissa bits.  They are read and written only by this kernel, each
-    // lane its own values, so they are stored in register order: the word of unit u (a channel tile x a pair of
-    // position tiles = 8 nibbles per lane) of lane l of wave `wave` of board group g sits at
-    // ((g * 8 + wave) * NU + u) * 64 + l - every wave access is one contiguous 256-byte run, there is no position
-    // arithmetic, and dead lanes simply own unused slots.
-    uint32_t* const log = SPLIT ? (uint32_t*)lo + ((size_t)g * 8 + wave) * (MTW * ((NTW + 1) / 2)) * 64 : nullptr;   // wave-uniform
+    uint32_t prow[NTW];   // element offset of the lane's position row in a chunk plane (32 elements per row)
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
       const int p = (wp * NTW + nt) * 16 + r16;
       live[nt] = p < PT && board0 + p / HW < B;
       uint32_t pbv = (uint32_t)pb[nt];
       asm volatile("" : "+v"(pbv));
-      obase[nt] = (pbv / 80u + (PW + 1)) * COUT;
+      prow[nt] = (pbv / 80u + (PW + 1)) * 32u;
     }
-    // Software-pipelined in units of (channel tile, PAIR of position tiles): the residual words of the unit NP
-    // units ahead (one channel tile's worth) are requested BEFORE the stores of the current unit are issued.
-    // vmcnt retires in order, so a load issued after stores could only be consumed once those stores had
-    // completed (a full HBM write round trip per tile).
-    constexpr int NP = (NTW + 1) / 2, NU = MTW * NP;
-    constexpr int DEPTH = (SPLIT && NP > 2) ? 2 : NP;   // units in flight (the split variants have no registers for more)
-    uint2 rrb[DEPTH][2];
-    uint32_t lwb[DEPTH];
-    auto load_unit = [&](int u, uint2 (&rr)[2], uint32_t& lw) {
-      const int mt = u / NP, p = u - mt * NP;
-      const int co = (wc * MTW + mt) * 16 + q * 4;
+    // bias first, one channel tile at a time (the next tile's four floats requested one tile ahead): (acc + bias) + skip,
+    // the same float operations as with the bias added per unit
+    {
+      float4 bv_next = *(const float4*)(bias + tile_of(0) * 16 + q * 4);
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int nt = 2 * p + k;
-        if (nt < NTW && res) rr[k] = live[nt] ? *(const uint2*)(resg + obase[nt] + co) : make_uint2(0, 0);
+      for (int mt = 0; mt < MTW; ++mt) {
+        const float4 bv = bv_next;
+        if (mt + 1 < MTW) bv_next = *(const float4*)(bias + tile_of(mt + 1) * 16 + q * 4);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) { acc[mt][nt][0] += bv.x; acc[mt][nt][1] += bv.y; acc[mt][nt][2] += bv.z; acc[mt][nt][3] += bv.w; }
+      }
+    }
+    // SPLIT: the skip stream's four extra mantissa bits.  They are read and written only by this kernel, each
+    // lane its own values, so they are stored in register order: the word of unit u (8 nibbles per lane) of lane l of
+    // wave `wave` of board group g sits at ((g * 8 + wave) * NU + u) * 64 + l - every wave access is one contiguous
+    // 256-byte run, there is no position arithmetic, and dead lanes simply own unused slots.
+    uint32_t* const log = SPLIT ? (uint32_t*)lo + ((size_t)g * 8 + wave) * NU * 64 : nullptr;   // wave-uniform
+    // unit u -> its two accumulator tiles (mtA, ntA), (mtB, ntB); hasB: false only for the last single unit of an odd NTW
+    struct Unit { int mtA, ntA, mtB, ntB; bool pair, hasB; };
+    auto unit_of = [](int u) {
+      if (u < MP * NTW) { const int k = u / NTW, nt = u - k * NTW; return Unit{2 * k, nt, 2 * k + 1, nt, true, true}; }
+      const int p = u - MP * NTW;
+      return Unit{MTW - 1, 2 * p, MTW - 1, 2 * p + 1 < NTW ? 2 * p + 1 : 2 * p, false, 2 * p + 1 < NTW};
+    };
+    // the lane's 16 bytes of unit u: plane base (wave-uniform), element offset, and whether the lane's position exists
+    struct Where { size_t plane; uint32_t off; bool lv; };
+    auto where = [&](const Unit& un) {
+      if (un.pair) {
+        const int chunk = wc * MP + un.mtA / 2;
+        return Where{(size_t)chunk * CS * 32, prow[un.ntA] + (uint32_t)((q & 1) * 16 + (q >> 1) * 8), live[un.ntA]};
+      }
+      const bool second = (q & 1) && un.hasB;
+      return Where{(size_t)(MTW - 1) * CS * 32, (second ? prow[un.ntB] : prow[un.ntA]) + (uint32_t)(wc * 16 + (q >> 1) * 8), second ? live[un.ntB] : live[un.ntA]};
+    };
+    // Software-pipelined: the skip words of the unit DEPTH units ahead are requested BEFORE the stores of the current
+    // unit are issued.  vmcnt retires in order, so a load issued after stores could only be consumed once those stores
+    // had completed (a full HBM write round trip per unit).
+    constexpr int DEPTH = NU < 3 ? NU : ((SPLIT && NTW > 4) ? 2 : 3);   // units in flight (the large split variants have no registers for more)
+    uint4 rrb[DEPTH];
+    uint32_t lwb[DEPTH];
+    auto load_unit = [&](int u, uint4& rr, uint32_t& lw) {
+      const Unit un = unit_of(u);
+      if (res) {
+        const Where w = where(un);
+        if (un.hasB) rr = w.lv ? *(const uint4*)(resg + w.plane + w.off) : make_uint4(0, 0, 0, 0);
+        else {   // one position tile only: 8 bytes per lane, channels 4q .. 4q+3 of the half chunk
+          const uint2 h = live[un.ntA] ? *(const uint2*)(resg + w.plane + prow[un.ntA] + (uint32_t)(wc * 16 + q * 4)) : make_uint2(0, 0);
+          rr = make_uint4(h.x, h.y, 0, 0);
+        }
       }
       if (SPLIT == 2) lw = log[u * 64 + lane];
     };
-    float4 bv_next = *(const float4*)(bias + (wc * MTW) * 16 + q * 4);
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u) load_unit(u, rrb[u], lwb[u]);
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) {
-      const int co = (wc * MTW + mt) * 16 + q * 4;
-      const float4 bv = bv_next;
-      if (mt + 1 < MTW) bv_next = *(const float4*)(bias + (wc * MTW + mt + 1) * 16 + q * 4);
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int u = mt * NP + p;
-        uint2 o[2];
-        const uint32_t lw = SPLIT == 2 ? lwb[u % DEPTH] : 0u;
-        uint32_t lwo = 0u;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int nt = 2 * p + k;
-          if (nt >= NTW) continue;
-          float v[4] = {acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w};
-          if (res) {
-            const uint2 rr = rrb[u % DEPTH][k];
-            uint32_t sb[4] = {rr.x << 16, rr.x & 0xFFFF0000u, rr.y << 16, rr.y & 0xFFFF0000u};
-            if (SPLIT == 2) {
-              // skip value = the 20-bit float whose bf16 rounding is the stored word: its bit pattern is
-              // (bf16 << 16) + (signed nibble << 12)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) sb[r] += (uint32_t)__builtin_amdgcn_sbfe((int)lw, (k * 4 + r) * 4, 4) << 12;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += __uint_as_float(sb[r]);
-          }
-          if (relu) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_relu(v[r], slope);
-          }
-          if (SPLIT) {
-            // v rounded to 20 bits (12 dropped, half up), then to bf16 (half up again): the bf16 word goes to the
-            // next convolution, bits 12..15 of the 20-bit pattern - read as a signed nibble they are exactly
-            // (20-bit pattern) - (bf16 word << 16) - to the skip stream
-            uint32_t t[4], h[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              t[r] = __float_as_uint(v[r]) + 0x800u;
-              h[r] = (t[r] & 0xFFFFF000u) + 0x8000u;
-              lwo |= ((t[r] >> 12) & 0xFu) << ((k * 4 + r) * 4);
-            }
-            o[k].x = (h[0] >> 16) | (h[1] & 0xFFFF0000u);
-            o[k].y = (h[2] >> 16) | (h[3] & 0xFFFF0000u);
-          } else {
-            o[k].x = pack_bf16(v[0], v[1]);
-            o[k].y = pack_bf16(v[2], v[3]);
-          }
-        }
-        if (u + DEPTH < NU) load_unit(u + DEPTH, rrb[u % DEPTH], lwb[u % DEPTH]);
-        // Stores are issue-bound, so make them 16 bytes wide: lanes q and q+1 (16 lanes apart) hold
-        // adjacent 4-channel groups.  v_permlane16_swap exchanges the odd 16-lane rows of one register
-        // with the even rows of another; applied to the words of a PAIR of position tiles it leaves
-        // rows 0/2 with channels [8(q/2), 8(q/2)+8) of the first tile and rows 1/3 with those of the second.
-        const int nt = 2 * p;
-        if (nt + 1 < NTW) {
-          const bool second = q & 1;
-          const uint32_t ob = (second ? obase[nt + 1] : obase[nt]) + (wc * MTW + mt) * 16 + (q >> 1) * 8;
-          const bool lv = second ? live[nt + 1] : live[nt];
-          const auto sx = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);
-          const auto sy = __builtin_amdgcn_permlane16_swap(o[0].y, o[1].y, false, false);
-          if (lv) *(uint4*)(outg + ob) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+    for (int u = 0; u < NU; ++u) {
+      const Unit un = unit_of(u);
+      uint2 o[2];
+      const uint32_t lw = SPLIT == 2 ? lwb[u % DEPTH] : 0u;
+      uint32_t lwo = 0u;
+      uint2 rr[2] = {make_uint2(0, 0), make_uint2(0, 0)};
+      if (res) {
+        const uint4 rv = rrb[u % DEPTH];
+        if (un.hasB) {   // back to the accumulator layout
+          const auto sx = __builtin_amdgcn_permlane16_swap(rv.x, rv.z, false, false);
+          const auto sy = __builtin_amdgcn_permlane16_swap(rv.y, rv.w, false, false);
+          rr[0] = make_uint2(sx[0], sy[0]); rr[1] = make_uint2(sx[1], sy[1]);
         } else {
-          if (live[nt]) *(uint2*)(outg + obase[nt] + co) = o[0];
+          rr[0] = make_uint2(rv.x, rv.y);
         }
-        if (SPLIT) log[u * 64 + lane] = lwo;
       }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (k == 1 && !un.hasB) continue;
+        const int mt = k ? un.mtB : un.mtA, nt = k ? un.ntB : un.ntA;
+        float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+        if (res) {
+          uint32_t sb[4] = {rr[k].x << 16, rr[k].x & 0xFFFF0000u, rr[k].y << 16, rr[k].y & 0xFFFF0000u};
+          if (SPLIT == 2) {
+            // skip value = the 20-bit float whose bf16 rounding is the stored word: its bit pattern is
+            // (bf16 << 16) + (signed nibble << 12)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sb[r] += (uint32_t)__builtin_amdgcn_sbfe((int)lw, (k * 4 + r) * 4, 4) << 12;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += __uint_as_float(sb[r]);
+        }
+        if (relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = act_relu(v[r], slope);
+        }
+        if (SPLIT) {
+          // v rounded to 20 bits (12 dropped, half up), then to bf16 (half up again): the bf16 word goes to the
+          // next convolution, bits 12..15 of the 20-bit pattern - read as a signed nibble they are exactly
+          // (20-bit pattern) - (bf16 word << 16) - to the skip stream
+          uint32_t t[4], h[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            t[r] = __float_as_uint(v[r]) + 0x800u;
+            h[r] = (t[r] & 0xFFFFF000u) + 0x8000u;
+            lwo |= ((t[r] >> 12) & 0xFu) << ((k * 4 + r) * 4);
+          }
+          o[k].x = (h[0] >> 16) | (h[1] & 0xFFFF0000u);
+          o[k].y = (h[2] >> 16) | (h[3] & 0xFFFF0000u);
+        } else {
+          o[k].x = pack_bf16(v[0], v[1]);
+          o[k].y = pack_bf16(v[2], v[3]);
+        }
+      }
+      if (u + DEPTH < NU) load_unit(u + DEPTH, rrb[u % DEPTH], lwb[u % DEPTH]);
+      const Where w = where(un);
+      if (un.hasB) {
+        const auto sx = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(o[0].y, o[1].y, false, false);
+        if (w.lv) *(uint4*)(outg + w.plane + w.off) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      } else {
+        if (live[un.ntA]) *(uint2*)(outg + w.plane + prow[un.ntA] + (uint32_t)(wc * 16 + q * 4)) = o[0];
+      }
+      if (SPLIT) log[u * 64 + lane] = lwo;
     }
     }
     CP_SEG(6);   // epilogue
@@ -876,7 +840,7 @@ conv3x3_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, con
 //   pi  = exp(logsoftmax(pi_linear(relu(bn(conv1x1_pi(s))))))     V = tanh(lin2(relu(lin1(relu(bn(conv1x1_v(s)))))))
 template <class T>
 __global__ void __launch_bounds__(256)
-net_heads_kernel(const T* __restrict__ x, const T* __restrict__ xlo, int H, int W, int C, int A,
+net_heads_kernel(const T* __restrict__ x, const T* __restrict__ xlo, long CS, int H, int W, int C, int A,
                  const float* __restrict__ wpi, const float* __restrict__ hsc, const float* __restrict__ wv,
                  const float* __restrict__ pl_w, const float* __restrict__ pl_b,
                  const float* __restrict__ v1_w, const float* __restrict__ v1_b,
@@ -893,14 +857,16 @@ net_heads_kernel(const T* __restrict__ x, const T* __restrict__ xlo, int H, int 
   const float bpi = hsc[0], bv = hsc[1], v2_b = hsc[2], slope = hsc[3];   // folded biases of the two 1x1 convolutions, value_linear2.bias
   for (int p = tid; p < HW; p += 256) {
     const int y = p / W, xw = p % W;
-    const size_t roff = (((size_t)n * (H + 2) + y + 1) * (W + 2) + xw + 1) * C;
+    const size_t prow = ((size_t)n * (H + 2) + y + 1) * (W + 2) + xw + 1;
+    const size_t roff = prow * C;      // NHWC (CS == 0)
     const T* row = x + roff;
     float a = 0.f, b = 0.f;
     if constexpr (sizeof(T) == 4) {
       for (int c = 0; c < C; ++c) { const float xv = (float)row[c]; a += xv * wpi[c]; b += xv * wv[c]; }
     } else {
       for (int c = 0; c < C; c += 8) {
-        const uint4 v = *(const uint4*)(row + c);
+        // CS > 0: the board kernel's chunk-major layout, 8 channels = 16 bytes inside the chunk's 64-byte row
+        const uint4 v = CS ? *(const uint4*)(x + ((size_t)(c >> 5) * CS + prow) * 32 + (c & 31)) : *(const uint4*)(row + c);
         const uint4 vl = xlo ? *(const uint4*)(xlo + roff + c) : make_uint4(0, 0, 0, 0);   // trunk output = hi + lo
         const uint32_t u[4] = {v.x, v.y, v.z, v.w}, ul[4] = {vl.x, vl.y, vl.z, vl.w};
 #pragma unroll
@@ -1176,7 +1142,7 @@ struct NetImpl {
     const int ngroups = (B + NBW - 1) / NBW;
     const int grid = persist_wgs > 0 ? std::min(ngroups, persist_wgs) : ngroups;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, x, c.wb, c.b, res, out, lo, B, c.cin,
-                       relu, cfg.leaky_slope, late_half, stagger >= 0 ? stagger : default_stagger<COUT, H, NBW>(c.cin), stagger_phases);
+                       relu, cfg.leaky_slope, late_half, stagger >= 0 ? stagger : default_stagger<COUT, H, NBW>(c.cin), stagger_phases, chunk_rows());
     return ELFHIP_OK;
   }
   template <int COUT>
@@ -1185,6 +1151,9 @@ struct NetImpl {
     if (cfg.board == 8) return launch_board<COUT, 8, 4>(x, c, res, out, lo, lo_in, B, relu);
     return 1;
   }
+  // rows per chunk plane of the board kernel's chunk-major activations (0: the generic kernels' NHWC).  Fixed per
+  // network: the zero borders of the padded boards then never move, whatever the batch of a call.
+  long chunk_rows() const { return board_shape() ? (long)max_batch * (cfg.board + 2) * (cfg.board + 2) : 0L; }
   bool board_shape() const {   // the shapes conv() sends to the board kernel
     if (!use_board_kernel) return false;
     const int d = cfg.dim;
@@ -1242,7 +1211,7 @@ struct NetImpl {
       cur = t2;
     }
     const size_t sm = ((size_t)2 * H * H + cfg.num_action + 256) * 4;
-    hipLaunchKernelGGL(net_heads_kernel<float>, dim3(B), dim3(256), sm, stream, fact[cur], (const float*)nullptr, H, H, cfg.dim, cfg.num_action, wpi, hsc,
+    hipLaunchKernelGGL(net_heads_kernel<float>, dim3(B), dim3(256), sm, stream, fact[cur], (const float*)nullptr, 0L, H, H, cfg.dim, cfg.num_action, wpi, hsc,
                        wv, pl_w, pl_b, v1_w, v1_b, v2_w, d_pi, d_logpi, d_v);
     HIPCHECK(hipGetLastError());
     return ELFHIP_OK;
@@ -1252,7 +1221,7 @@ struct NetImpl {
     if (f32) return forward_f32(d_s, B, d_pi, d_logpi, d_v);
     const int H = cfg.board;
     hipLaunchKernelGGL(net_pack_input_kernel, dim3(std::min<size_t>(4096, ((size_t)B * H * H * cin_pad + 255) / 256)), dim3(256),
-                       0, stream, d_s, xin, B, cfg.planes, H, H, cin_pad);
+                       0, stream, d_s, xin, B, cfg.planes, H, H, cin_pad, chunk_rows());
     uint16_t* const slo = split_skip ? lo : nullptr;
     int rc = conv(xin, convs[0], nullptr, act[0], slo, 0, B, 1);             // init_conv: conv + BN + ReLU
     int cur = 0;
@@ -1266,7 +1235,7 @@ struct NetImpl {
     const size_t sm = ((size_t)2 * H * H + cfg.num_action + 256) * 4;
     // the generic kernel's `lo` is a second bf16 array the heads can add; the board kernel's nibbles are private to it
     const uint16_t* const hlo = board_shape() ? nullptr : slo;
-    hipLaunchKernelGGL(net_heads_kernel<uint16_t>, dim3(B), dim3(256), sm, stream, act[cur], hlo, H, H, cfg.dim, cfg.num_action, wpi, hsc, wv,
+    hipLaunchKernelGGL(net_heads_kernel<uint16_t>, dim3(B), dim3(256), sm, stream, act[cur], hlo, chunk_rows(), H, H, cfg.dim, cfg.num_action, wpi, hsc, wv,
                        pl_w, pl_b, v1_w, v1_b, v2_w, d_pi, d_logpi, d_v);
     HIPCHECK(hipGetLastError());
     return ELFHIP_OK;
