@@ -7,7 +7,8 @@ DEF=$1
 cd "$(dirname "$0")/.."
 OUT=benchmarks/_prof
 mkdir -p $OUT/obj_$DEF
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function -Wno-inline-asm -D$DEF"
+DEFS=""; for d in ${DEF//,/ }; do DEFS="$DEFS -D$d"; done
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function -Wno-inline-asm $DEFS"
 pids=()
 for s in elf_amd/csrc/*.hip; do
   o=$OUT/obj_$DEF/$(basename ${s%.hip}).o
