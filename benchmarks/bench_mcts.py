@@ -88,7 +88,7 @@ def measure(games=16384, moves=12, warmup=2, batch=8):
            "config": {"workload": "American checkers batched self-play, %d games, uniform-policy MCTS, 256 rollouts/move, batch %d, vloss 1, c_puct 1.5 (BASELINE.json configs[2])" % (n, a.batch)},
            "parked_trees": int((flags != 0).sum().item()),
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                        "traffic": None, "kernel": "mcts_search_kernel<0>", "kernel_ms": kern_ms,
+                        "traffic": None, "kernel": "quad_search_kernel<AmQuad> (four trees per wave)" if os.environ.get("ELFHIP_MCTS_QUAD", "1") != "0" else "mcts_search_kernel<0>", "kernel_ms": kern_ms,
                         "mean_depth": D, "mean_branching": b, "algorithmic_bytes_per_rollout": bytes_per_rollout}}
     return out
 

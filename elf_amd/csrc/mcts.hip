@@ -10,12 +10,14 @@
 //   elfgames/american_checkers/mcts/MCTSGameActor.h:198-335 (pre_evaluate, pi2response)
 // including the float/double mix in getScore and the libstdc++ orders (stdorder.h) that decide
 // every tie.  What is different is the machinery: no mutexes, no heap nodes, no hash maps.
-// A tree is two ping-pong arenas in HBM (nodes + a struct-of-arrays edge pool; a node's edges are
-// contiguous and already stored in unordered_map iteration order, so the UCT scan is one coalesced
-// read); treeAdvance compacts the kept subtree into the other arena with a breadth-first copy.
+// A tree lives in one arena of a pool in HBM (64-byte node records, 8-byte edges; a node's edges are contiguous
+// and already stored in unordered_map iteration order, so the UCT scan is one coalesced read; mcts_core.h);
+// treeAdvance compacts the kept subtree into a spare arena with a breadth-first copy.
+// The fused uniform-policy search (run_uniform) runs four trees per wave (mcts_quad.h).
 #include <cstring>
 #include "american_dev.h"
 #include "mcts_core.h"
+#include "mcts_quad.h"
 
 namespace {
 using namespace amdev;
@@ -50,6 +52,27 @@ struct AmGame {
     am_play(s, action, c_acttab.fam[action], c_acttab.shift[action]);
     store_board(node_board(tv, child), s);
     tv.meta[child] = NOT_VISITED | META_STATE_SET;
+  }
+};
+
+// the game as mcts_quad.h's four-trees-per-wave kernel takes it (the interface of mcts_games.hip's adaptors)
+struct AmQuad {
+  static constexpr int NA = ::NA, MAXLEGAL = ::MAXLEGAL, W64 = AM_SW / 2, MW = 3;
+  using S = Am;
+  __device__ static void load(const uint64_t* p, S& s) { load_board(p, s); }
+  __device__ static void store(uint64_t* p, const S& s) { store_board(p, s); }
+  __device__ static void play(S& s, int action) { am_play(s, action, c_acttab.fam[action], c_acttab.shift[action]); }
+  // pre_evaluate (MCTSGameActor.h:198-218): terminated() (GameState.h:51-53), evaluateGame (GameState.cc:65-77), q_flip, legal mask
+  __device__ static void eval(const S& s0, uint64_t mk[MW], bool& terminal, bool& flip, float& tvalue) {
+    S s = s0;
+    uint64_t fam[8];
+    am_families(s, fam);
+    const int total = am_count(fam);
+    flip = am_active(s) == 1;
+    terminal = total == 0 || am_ply(s) >= 250;
+    tvalue = (am_ply(s) < 250 && am_active(s) == 1) ? 1.0f : -1.0f;
+    mk[0] = mk[1] = mk[2] = 0;
+    if (!terminal) { am_apply_repeat_rule(s, fam, total); am_mask_words(fam, mk); }
   }
 };
 
@@ -272,6 +295,11 @@ struct AmericanMcts : MctsBase {
     return ELFHIP_OK;
   }
   int run_uniform() override {
+    if (quad_enabled()) {   // four trees per wave (mcts_quad.h)
+      hipLaunchKernelGGL(quad_search_kernel<AmQuad>, dim3((d.n_trees + 3) / 4), dim3(64), 0, stream, d, o);
+      HIPCHECK(hipGetLastError());
+      return ELFHIP_OK;
+    }
     hipLaunchKernelGGL(mcts_search_kernel<0>, dim3(d.n_trees), dim3(64), 0, stream, d, x, o, (uint64_t*)nullptr,
                        (float*)nullptr, (uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
     HIPCHECK(hipGetLastError());

@@ -662,6 +662,9 @@ struct MctsBase {
   uint16_t* uniform_order = nullptr;
   virtual ~MctsBase() { for (void* p : allocs) (void)hipFree(p); }
 
+  // ELFHIP_MCTS_QUAD=0: the uniform-policy search of the checkers-family games on the one-tree-per-wave kernel
+  // (tests run both; same trees bit for bit)
+  static bool quad_enabled() { const char* e = getenv("ELFHIP_MCTS_QUAD"); return !(e && e[0] == '0'); }
   // game specific
   virtual int set_roots(BoardSlab* slab, uint8_t* d_ok) = 0;
   virtual int run_uniform() = 0;
@@ -688,9 +691,16 @@ struct MctsBase {
     }
     if (d.max_nodes > MAX_NODES_LIMIT) d.max_nodes = MAX_NODES_LIMIT;
     d.max_edges = opt->max_edges > 0 ? opt->max_edges : default_edges_per_node * d.max_nodes;
-    // spare arenas for treeAdvance: every tree at once while that is cheap, a sixteenth of the trees (sixteen
-    // launches per move) when the trees are what fills the GPU's memory
-    d.n_spare = n_trees <= 1024 ? n_trees : (n_trees / 16 > 1024 ? n_trees / 16 : 1024);
+    // spare arenas for treeAdvance: every tree at once while that is cheap (up to 8 GiB of spares: one launch per
+    // move - 16,384 checkers trees advance in a quarter of the time sixteen chunked launches take), a sixteenth of
+    // the trees (sixteen launches per move) when the trees are what fills the GPU's memory
+    {
+      const size_t per_tree = (size_t)d.max_nodes * (NODE_BYTES + 4 * (size_t)state_words) + (size_t)d.max_edges * EDGE_BYTES;
+      size_t cheap = ((size_t)8 << 30) / (per_tree ? per_tree : 1);
+      if (cheap < 1024) cheap = 1024;
+      if (cheap < (size_t)n_trees / 16) cheap = (size_t)n_trees / 16;
+      d.n_spare = (size_t)n_trees <= cheap ? n_trees : (int)cheap;
+    }
     if (const char* e = getenv("ELFHIP_MCTS_SPARE_ARENAS")) {   // tests: force the chunked advance on small searches
       const int v = atoi(e);
       if (v >= 1 && v <= n_trees) d.n_spare = v;

@@ -7,6 +7,7 @@
 // std::sort of all (action, pi) pairs, checkMove filter, normalise.  Neither game keeps a board
 // history in its feature planes, so a leaf's planes depend on the leaf state only.
 #include "mcts_core.h"
+#include "mcts_quad.h"
 #include "russian_dev.h"
 #include "ugolki_dev.h"
 
@@ -194,6 +195,11 @@ struct GameMcts : MctsBase {
     return ELFHIP_OK;
   }
   int run_uniform() override {
+    if (quad_enabled()) {   // four trees per wave (mcts_quad.h)
+      hipLaunchKernelGGL(quad_search_kernel<G>, dim3((d.n_trees + 3) / 4), dim3(64), 0, stream, d, o);
+      HIPCHECK(hipGetLastError());
+      return ELFHIP_OK;
+    }
     hipLaunchKernelGGL((games_search_kernel<G, 0>), dim3(d.n_trees), dim3(64), 0, stream, d, o, (uint64_t*)nullptr,
                        (float*)nullptr, (uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
     HIPCHECK(hipGetLastError());

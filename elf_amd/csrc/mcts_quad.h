@@ -1,0 +1,288 @@
+// Uniform-policy tree search with FOUR trees per wavefront (16 lanes each) for the checkers-family games.
+//
+// mcts_core.h gives one tree a whole 64-lane wave; a checkers node has ~5.5 edges, so 58 of the 64 lanes idle
+// through the UCT scoring while the wave's instruction stream - descent bookkeeping, the game move, the hashtable
+// order - is paid per tree.  Here a 16-lane group owns a tree: everything that mcts_core.h keeps wave-uniform is
+// kept group-uniform in vector registers, every step is executed once for four trees, and a group that has
+// nothing to do in a step is masked.  The arithmetic, the orders of the float sums and every tie-break are those
+// of select_one / expand_prepare / backup_batch (and therefore of the reference, see mcts_core.h): the two kernels
+// produce bit-identical trees (tests/test_gpu_mcts.py runs both against the oracle).
+//
+// Only the fused uniform-policy search (TreeSearchT::run with a uniform evaluator: BASELINE.json configs[2]) runs
+// here; the select / backup halves used with a network stay one wave per tree (the network dominates there).
+#pragma once
+#include "mcts_core.h"
+
+namespace mcts {
+
+template <class G>
+struct QuadScratch {   // per 16-lane group
+  uint16_t keys[G::MAXLEGAL], pos[G::MAXLEGAL], seq[G::MAXLEGAL];
+  int rkey[G::MAXLEGAL];
+  int table[G::MAXLEGAL <= 59 ? 64 : (G::MAXLEGAL <= 127 ? 128 : 272)];
+  int leaf[MAXB], locked[MAXB];
+};
+
+__device__ inline uint32_t gballot(bool p, int g) { return (uint32_t)(__ballot(p) >> (g * 16)) & 0xFFFFu; }
+template <class T>
+__device__ inline T gbcast(T v, int k, int lane) { return __shfl(v, (lane & 48) | k); }
+
+// std::unordered_map iteration order of keys[0..m) (stdorder::umap_iteration_order_wave for one 16-lane group; the
+// four groups of the wave run it together, each on its own keys with its own m).  run: the group takes part.
+template <int NB>
+__device__ inline void umap_epoch_group(bool on, const uint16_t* keys, int cnt, int end, int gl, const uint16_t* src, uint16_t* dst,
+                                        int* rkey, int* table) {
+  if (on) for (int b = gl; b < NB; b += 16) table[b] = 0x7fffffff;
+  stdorder::wave_sync();
+  if (on) for (int i = gl; i < end; i += 16) {
+    const int p = i < cnt ? (int)src[i] : i;
+    atomicMin(&table[(int)keys[p] % NB], i);
+  }
+  stdorder::wave_sync();
+  if (on) for (int i = gl; i < end; i += 16) {
+    const int p = i < cnt ? (int)src[i] : i;
+    rkey[i] = table[(int)keys[p] % NB] * 1024 + i;
+  }
+  stdorder::wave_sync();
+  if (on) for (int c = 0; c < end; c += 16) {
+    const int i = c + gl;
+    const bool in = i < end;
+    const int mine = rkey[in ? i : 0];
+    int before = 0;
+    for (int e = 0; e < end; ++e) before += rkey[e] > mine ? 1 : 0;
+    if (in) dst[before] = (uint16_t)(i < cnt ? (int)src[i] : i);
+  }
+  stdorder::wave_sync();
+}
+
+template <int MAXLEGAL>
+__device__ inline void umap_order_group(bool run, const uint16_t* keys, int m, int gl, uint16_t* seq, int* rkey, int* table, uint16_t* out) {
+  run = run && m > 0;
+  const int passes = 1 + (m > 13) + (m > 29) + (m > 59) + (m > 127);
+  uint16_t* dst = (passes & 1) ? out : seq;   // ping-pong so that the group's last pass writes out
+  uint16_t* src = (passes & 1) ? seq : out;
+#define ELF_QUAD_PASS(CNT, NB, NEXT)                                                                          \
+  if (MAXLEGAL > CNT && __any(run && m > CNT)) {                                                             \
+    const bool on = run && m > CNT;                                                                          \
+    umap_epoch_group<NB>(on, keys, CNT, m < NEXT ? m : NEXT, gl, src, dst, rkey, table);                     \
+    if (on) { uint16_t* t = src; src = dst; dst = t; }                                                       \
+  }
+  ELF_QUAD_PASS(0, 13, 13)
+  ELF_QUAD_PASS(13, 29, 29)
+  ELF_QUAD_PASS(29, 59, 59)
+  ELF_QUAD_PASS(59, 127, 127)
+  ELF_QUAD_PASS(127, 257, 257)
+#undef ELF_QUAD_PASS
+}
+
+// G: the game (mcts_games.hip's static interface: NA, MAXLEGAL, W64, MW, S, load / store / play / eval).
+template <class G>
+__global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
+  __shared__ QuadScratch<G> SS[4];
+  const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
+  const int t = blockIdx.x * 4 + g;
+  const bool exists = t < d.n_trees;
+  const int tt = exists ? t : 0;
+  QuadScratch<G>& S = SS[g];
+  int flags = exists ? d.t_flags[tt] : FLAG_INACTIVE;
+  const bool entered = exists && flags == 0;          // overflowed / mismatched / inactive trees are parked
+  TV tv = tree_view(d, tt);
+  int nn = d.t_nnodes[tt], ne_cnt = d.t_nedges[tt];
+  unsigned long long rollouts = 0, evals = 0, depth_sum = 0, edge_sum = 0;
+  const int nbatch = (o.R + o.B - 1) / o.B;
+  auto gstate = [&](int node) { return (uint64_t*)(tv.state + (size_t)node * (2 * G::W64)); };
+  for (int batch = 0; batch < nbatch; ++batch) {
+    const bool alive = entered && flags == 0;         // as the one-tree kernel: a batch that parks the tree is its last
+    if (!__any(alive)) break;
+    // ---- select: B descents (single_rollout, tree_search.h:319-378) ----
+    for (int j = 0; j < o.B; ++j) {
+      uint16_t* tn = d.traj_node + ((size_t)tt * o.B + j) * MAXD;
+      int node = 0, depth = 0;
+      bool run = alive;
+      while (__any(run)) {
+        uint4 h0 = make_uint4(0, 0, 0, 0), h1 = make_uint4(0, 0, 0, 0);
+        if (run) {
+          h0 = *(const uint4*)(tv.meta.p + (size_t)node * NODE_BYTES);        // meta, ebase, visits, V
+          h1 = *(const uint4*)(tv.meta.p + (size_t)node * NODE_BYTES + 16);   // meanQ, parentQ, parent, paction
+        }
+        const uint32_t meta = h0.x;
+        const int ne = (int)(meta >> 16);
+        bool go = run && (meta & 0xFF) == VISITED && ne != 0;
+        if (go && depth >= MAXD) { flags |= FLAG_DEPTH_OVERFLOW; go = false; }
+        run = go;
+        if (!__any(go)) break;
+        const bool flip = (meta & META_FLIP) != 0;
+        const int eb = (int)h0.y;
+        float mq = __uint_as_float(h1.x);
+        if (o.uqz || (o.ruqz && depth == 0)) mq = 0.0f;
+        const float pq = __uint_as_float(h1.y);
+        const int nv = (int)h0.z;
+        const double sq = sqrt((double)(nv + 1));
+        float best = -INFINITY; int bestj = 0x7FFFFFFF, bestc = NOCHILD;
+        float bestvl = 0.f, total_uq = 0.f; int total_cnt = 0;
+        for (int base = 0; __any(go && base < ne); base += 16) {
+          const int jj = base + gl;
+          const bool ok = go && jj < ne;
+          float score = -INFINITY, uq = 0.f, vloss = 0.f; int counted = 0, cj = NOCHILD;
+          if (ok) {  // EdgeInfo::getScore tree_search_base.h:175-201
+            const uint2 e = *(const uint2*)(tv.ep.p + (size_t)(eb + jj) * EDGE_BYTES);
+            const float prior = __uint_as_float(e.x);
+            cj = (int)(e.y >> 16);
+            float reward = 0.f; int visits = 0;
+            if (cj != NOCHILD) {
+              const uint4 st = *(const uint4*)(tv.in_r.p + (size_t)cj * NODE_BYTES);
+              reward = __uint_as_float(st.x); visits = (int)st.y; vloss = __uint_as_float(st.z);
+            }
+            float r = flip ? -reward : reward;
+            r -= vloss;
+            const int nvl = (int)((float)visits + vloss);
+            const float q = nvl > 0 ? r / (float)nvl : (flip ? -mq : mq);
+            uq = visits > 0 ? reward / (float)visits : mq;
+            const float u = (float)((double)(prior / (float)(1 + visits)) * sq);
+            score = o.use_prior ? (u * o.c_puct + q) : q;
+            counted = nvl != 0;
+            if (ne > 16 && !(score == score)) score = -INFINITY;   // as select_one's wide path: a NaN never wins
+          }
+          const uint32_t cmask = gballot(counted != 0, g);
+          // the reference's own loop over the edges, in edge order, on values broadcast inside the group
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const float sk = gbcast(score, k, lane);
+            const float uk = gbcast(uq, k, lane);
+            const bool valid = go && base + k < ne;
+            if (valid && (sk > best || bestj == 0x7FFFFFFF)) { best = sk; bestj = base + k; }
+            if (valid && ((cmask >> k) & 1)) { total_uq += uk; total_cnt++; }
+          }
+          const int sel = (bestj >= base && bestj < base + 16) ? bestj - base : 0;
+          const int cs = gbcast(cj, sel, lane);
+          const float vs = gbcast(vloss, sel, lane);
+          if (go && bestj >= base && bestj < base + 16) { bestc = cs; bestvl = vs; }
+        }
+        const float mqn = (pq + total_uq) / (float)(total_cnt + 1);  // tree_search_node.h:240-241
+        if (go) tv.meanQ[node] = mqn;
+        int child = bestc;
+        if (go && child == NOCHILD) {  // followEdge :295-317 + allocateState tree_search.h:209-224
+          if (nn >= d.max_nodes) { flags |= FLAG_NODE_OVERFLOW; go = false; run = false; }   // parked; this step is not recorded
+          else {
+            child = nn++;
+            const int e = eb + bestj;
+            const int action = tv.ea[e];
+            init_node(tv, child, mqn, node, action);
+            typename G::S s;
+            G::load(gstate(node), s);
+            G::play(s, action);
+            G::store(gstate(child), s);
+            tv.meta[child] = NOT_VISITED | META_STATE_SET;
+            tv.ec[e] = (uint16_t)child;
+            bestvl = 0.f;
+          }
+        }
+        if (go) {
+          if (o.vl > 0) tv.in_l[child] = bestvl + (float)o.vl;  // addVirtualLoss :246-264
+          tn[depth] = (uint16_t)node;
+        }
+        __threadfence_block();
+        if (go) { node = child; ++depth; }
+      }
+      if (alive) {
+        d.traj_len[(size_t)tt * o.B + j] = depth;
+        rollouts += 1; depth_sum += (unsigned long long)depth;
+        // requestEvaluation tree_search_node.h:169-179
+        const uint32_t meta = tv.meta[node];
+        const int lock = (meta & 0xFF) == NOT_VISITED;
+        if (lock) tv.meta[node] = (meta & ~0xFFu) | EVAL_REQUESTED;
+        S.leaf[j] = node; S.locked[j] = lock;
+      }
+      __threadfence_block();
+    }
+    stdorder::wave_sync();
+    // ---- setEvaluation of the locked leaves, uniform evaluator (pi = 1 / NA, V = 0) ----
+    for (int j = 0; j < o.B; ++j) {
+      const bool ex = alive && S.locked[j] != 0;
+      if (!__any(ex)) continue;
+      const int leaf = ex ? S.leaf[j] : 0;
+      typename G::S s;
+      G::load(gstate(leaf), s);
+      uint64_t mk[G::MW]; bool terminal, flip; float value;
+      G::eval(s, mk, terminal, flip, value);   // pre_evaluate (actor :198-218)
+      if (!terminal) value = 0.0f;
+      const bool fill = ex && !terminal;
+      int m = 0;
+      const int eb = ne_cnt;
+      if (fill) evals += 1;
+      // checkMove filter over the std::sort order of NA equal keys: the legal items keep that order
+      int kept = 0;
+      for (int c = 0; c < G::NA; c += 16) {
+        const int i = c + gl;
+        const bool in = i < G::NA;
+        const int a = in ? (int)d.uniform_order[i] : 0;
+        uint64_t word = 0;
+#pragma unroll
+        for (int q = 0; q < G::MW; ++q) word = (a >> 6) == q ? mk[q] : word;
+        const bool legal = fill && in && ((word >> (a & 63)) & 1);
+        const uint32_t b = gballot(legal, g);
+        const int pos = kept + __popc(b & ((1u << gl) - 1u));
+        if (legal && pos < G::MAXLEGAL) S.keys[pos] = (uint16_t)a;
+        kept += __popc(b);
+      }
+      stdorder::wave_sync();
+      const bool over = kept > G::MAXLEGAL;
+      const int mm = fill ? (over ? G::MAXLEGAL : kept) : 0;
+      // normalize (:240-251): the float sum of mm equal priors in order, then one division
+      const float pri = 1.0f / (float)G::NA;
+      float tot = 1e-10f;
+      for (int k = 0; __any(k < mm); ++k) if (k < mm) tot += pri;
+      const float prior = pri / tot;
+      umap_order_group<G::MAXLEGAL>(fill, S.keys, mm, gl, S.seq, S.rkey, S.table, S.pos);
+      if (fill) {
+        m = mm;
+        if (over) { flags |= FLAG_LEGAL_OVERFLOW; m = 0; }
+        if (eb + m > d.max_edges) { flags |= FLAG_EDGE_OVERFLOW; m = 0; }
+        ne_cnt += m;
+        edge_sum += (unsigned long long)m;
+      }
+      if (ex) {
+        for (int jj = gl; jj < m; jj += 16) {
+          const int p = S.pos[jj];
+          *(uint2*)(tv.ep.p + (size_t)(eb + jj) * EDGE_BYTES) = make_uint2(__float_as_uint(prior), (uint32_t)S.keys[p] | ((uint32_t)NOCHILD << 16));
+        }
+        *(uint4*)(tv.meta.p + (size_t)leaf * NODE_BYTES) =
+            make_uint4(VISITED | (flip ? META_FLIP : 0u) | META_STATE_SET | ((uint32_t)m << 16), (uint32_t)eb, 0u, __float_as_uint(value));
+      }
+      stdorder::wave_sync();
+    }
+    // ---- backup (tree_search.h:291-305 + updateEdgeStats tree_search_node.h:267-292) ----
+    for (int j = 0; j < o.B; ++j) {
+      const int leaf = alive ? S.leaf[j] : -1;
+      bool first = alive; int count = 0;
+      for (int k = 0; k < o.B; ++k) if (alive && S.leaf[k] == leaf) { if (k < j) first = false; ++count; }
+      if (__any(first)) {
+        const float reward = first ? tv.V[leaf] : 0.f;
+        const int len = first ? d.traj_len[(size_t)tt * o.B + j] : 0;
+        const uint16_t* tn = d.traj_node + ((size_t)tt * o.B + j) * MAXD;
+        for (int i0 = 0; __any(i0 < len); i0 += 16) {
+          const int i = i0 + gl;
+          if (i < len) {
+            const int node = tn[i];
+            const int child = i + 1 < len ? (int)tn[i + 1] : leaf;
+            tv.visits[node] = tv.visits[node] + 1;
+            uint4* st = (uint4*)(tv.in_r.p + (size_t)child * NODE_BYTES);   // {reward, num_visits, virtual_loss, -}
+            const uint4 x = *st;
+            *st = make_uint4(__float_as_uint(__uint_as_float(x.x) + reward), x.y + 1u,
+                             __float_as_uint(__uint_as_float(x.z) - (float)(o.vl * count)), x.w);
+          }
+        }
+      }
+      stdorder::wave_sync();   // trajectories (which share the nodes near the root) stay in order
+    }
+  }
+  if (entered && gl == 0) {
+    d.t_nnodes[tt] = nn; d.t_nedges[tt] = ne_cnt; d.t_flags[tt] = flags;
+    if (rollouts) atomicAdd(&d.stats[0], rollouts);
+    if (evals) atomicAdd(&d.stats[1], evals);
+    if (depth_sum) atomicAdd(&d.stats[2], depth_sum);
+    if (edge_sum) atomicAdd(&d.stats[3], edge_sum);
+  }
+}
+
+}  // namespace mcts
