@@ -11,6 +11,7 @@
 // Only the fused uniform-policy search (TreeSearchT::run with a uniform evaluator: BASELINE.json configs[2]) runs
 // here; the select / backup halves used with a network stay one wave per tree (the network dominates there).
 #pragma once
+#include <utility>
 #include "mcts_core.h"
 
 namespace mcts {
@@ -26,6 +27,13 @@ struct QuadScratch {   // per 16-lane group
 __device__ inline uint32_t gballot(bool p, int g) { return (uint32_t)(__ballot(p) >> (g * 16)) & 0xFFFFu; }
 template <class T>
 __device__ inline T gbcast(T v, int k, int lane) { return __shfl(v, (lane & 48) | k); }
+// lane K of each 16-lane group to the whole group: a DPP row broadcast (no LDS round trip); K is a constant
+template <int K>
+__device__ inline float rowbcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, false));
+}
+template <class F, int... K>
+__device__ inline void for_each_k(F&& f, std::integer_sequence<int, K...>) { (f(std::integral_constant<int, K>{}), ...); }
 
 // std::unordered_map iteration order of keys[0..m) (stdorder::umap_iteration_order_wave for one 16-lane group; the
 // four groups of the wave run it together, each on its own keys with its own m).  run: the group takes part.
@@ -99,12 +107,19 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
       uint16_t* tn = d.traj_node + ((size_t)tt * o.B + j) * MAXD;
       int node = 0, depth = 0;
       bool run = alive;
+      // The search is a chain of dependent memory round trips (four waves per SIMD do not hide them), so the chain is
+      // kept short: only the root's header is loaded by itself.  A child's whole record comes with the edge
+      // statistics that live in it (same 64-byte line), and the chosen child's header is handed to the next level
+      // out of the lane that holds it; a node created here has a known header.  Nothing written on the way down
+      // (the parent's meanQ, the child's virtual loss) is part of what is handed on.
+      uint4 h0 = make_uint4(0, 0, 0, 0);       // meta, ebase, visits, V of `node`
+      float h_mq = 0.f, h_pq = 0.f;            // its meanQ, parentQ
+      if (run) {
+        h0 = *(const uint4*)(tv.meta.p);
+        const uint4 h1 = *(const uint4*)(tv.meta.p + 16);
+        h_mq = __uint_as_float(h1.x); h_pq = __uint_as_float(h1.y);
+      }
       while (__any(run)) {
-        uint4 h0 = make_uint4(0, 0, 0, 0), h1 = make_uint4(0, 0, 0, 0);
-        if (run) {
-          h0 = *(const uint4*)(tv.meta.p + (size_t)node * NODE_BYTES);        // meta, ebase, visits, V
-          h1 = *(const uint4*)(tv.meta.p + (size_t)node * NODE_BYTES + 16);   // meanQ, parentQ, parent, paction
-        }
         const uint32_t meta = h0.x;
         const int ne = (int)(meta >> 16);
         bool go = run && (meta & 0xFF) == VISITED && ne != 0;
@@ -113,24 +128,32 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
         if (!__any(go)) break;
         const bool flip = (meta & META_FLIP) != 0;
         const int eb = (int)h0.y;
-        float mq = __uint_as_float(h1.x);
+        float mq = h_mq;
         if (o.uqz || (o.ruqz && depth == 0)) mq = 0.0f;
-        const float pq = __uint_as_float(h1.y);
+        const float pq = h_pq;
         const int nv = (int)h0.z;
         const double sq = sqrt((double)(nv + 1));
         float best = -INFINITY; int bestj = 0x7FFFFFFF, bestc = NOCHILD;
         float bestvl = 0.f, total_uq = 0.f; int total_cnt = 0;
+        int besta = 0;                                  // the chosen edge's action
+        uint4 n0 = make_uint4(0, 0, 0, 0);              // the chosen child's header
+        float n_mq = 0.f, n_pq = 0.f;
         for (int base = 0; __any(go && base < ne); base += 16) {
           const int jj = base + gl;
           const bool ok = go && jj < ne;
-          float score = -INFINITY, uq = 0.f, vloss = 0.f; int counted = 0, cj = NOCHILD;
+          float score = -INFINITY, uq = 0.f, vloss = 0.f; int counted = 0, cj = NOCHILD, aj = 0;
+          uint4 c0 = make_uint4(0, 0, 0, 0); float c_mq = 0.f, c_pq = 0.f;
           if (ok) {  // EdgeInfo::getScore tree_search_base.h:175-201
             const uint2 e = *(const uint2*)(tv.ep.p + (size_t)(eb + jj) * EDGE_BYTES);
             const float prior = __uint_as_float(e.x);
-            cj = (int)(e.y >> 16);
+            cj = (int)(e.y >> 16); aj = (int)(e.y & 0xFFFFu);
             float reward = 0.f; int visits = 0;
             if (cj != NOCHILD) {
-              const uint4 st = *(const uint4*)(tv.in_r.p + (size_t)cj * NODE_BYTES);
+              const char* rec = tv.meta.p + (size_t)cj * NODE_BYTES;
+              c0 = *(const uint4*)rec;
+              const uint4 c1 = *(const uint4*)(rec + 16);
+              const uint4 st = *(const uint4*)(rec + 32);
+              c_mq = __uint_as_float(c1.x); c_pq = __uint_as_float(c1.y);
               reward = __uint_as_float(st.x); visits = (int)st.y; vloss = __uint_as_float(st.z);
             }
             float r = flip ? -reward : reward;
@@ -145,18 +168,20 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
           }
           const uint32_t cmask = gballot(counted != 0, g);
           // the reference's own loop over the edges, in edge order, on values broadcast inside the group
-#pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            const float sk = gbcast(score, k, lane);
-            const float uk = gbcast(uq, k, lane);
+          for_each_k([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const float sk = rowbcast<k>(score);
+            const float uk = rowbcast<k>(uq);
             const bool valid = go && base + k < ne;
             if (valid && (sk > best || bestj == 0x7FFFFFFF)) { best = sk; bestj = base + k; }
             if (valid && ((cmask >> k) & 1)) { total_uq += uk; total_cnt++; }
-          }
+          }, std::make_integer_sequence<int, 16>{});
           const int sel = (bestj >= base && bestj < base + 16) ? bestj - base : 0;
-          const int cs = gbcast(cj, sel, lane);
+          const int cs = gbcast(cj, sel, lane), as = gbcast(aj, sel, lane);
           const float vs = gbcast(vloss, sel, lane);
-          if (go && bestj >= base && bestj < base + 16) { bestc = cs; bestvl = vs; }
+          const uint4 s0 = make_uint4(gbcast(c0.x, sel, lane), gbcast(c0.y, sel, lane), gbcast(c0.z, sel, lane), gbcast(c0.w, sel, lane));
+          const float smq = gbcast(c_mq, sel, lane), spq = gbcast(c_pq, sel, lane);
+          if (go && bestj >= base && bestj < base + 16) { bestc = cs; bestvl = vs; besta = as; n0 = s0; n_mq = smq; n_pq = spq; }
         }
         const float mqn = (pq + total_uq) / (float)(total_cnt + 1);  // tree_search_node.h:240-241
         if (go) tv.meanQ[node] = mqn;
@@ -166,7 +191,7 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
           else {
             child = nn++;
             const int e = eb + bestj;
-            const int action = tv.ea[e];
+            const int action = besta;
             init_node(tv, child, mqn, node, action);
             typename G::S s;
             G::load(gstate(node), s);
@@ -175,6 +200,7 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
             tv.meta[child] = NOT_VISITED | META_STATE_SET;
             tv.ec[e] = (uint16_t)child;
             bestvl = 0.f;
+            n0 = make_uint4(NOT_VISITED | META_STATE_SET, 0u, 0u, 0u); n_mq = mqn; n_pq = mqn;   // the record just written
           }
         }
         if (go) {
@@ -182,13 +208,13 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
           tn[depth] = (uint16_t)node;
         }
         __threadfence_block();
-        if (go) { node = child; ++depth; }
+        if (go) { node = child; ++depth; h0 = n0; h_mq = n_mq; h_pq = n_pq; }
       }
       if (alive) {
         d.traj_len[(size_t)tt * o.B + j] = depth;
         rollouts += 1; depth_sum += (unsigned long long)depth;
-        // requestEvaluation tree_search_node.h:169-179
-        const uint32_t meta = tv.meta[node];
+        // requestEvaluation tree_search_node.h:169-179 (h0 is the header of the node the descent stopped at)
+        const uint32_t meta = h0.x;
         const int lock = (meta & 0xFF) == NOT_VISITED;
         if (lock) tv.meta[node] = (meta & ~0xFFu) | EVAL_REQUESTED;
         S.leaf[j] = node; S.locked[j] = lock;
