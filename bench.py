@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--nn-max-nodes", type=int, default=0, help="tree arena size in nodes (0 = 1,600 + 800 + 64)")
     ap.add_argument("--nn-batches", type=int, default=0, help="search batches per move (0 = all 200; fewer = a partial move, for sizing runs only)")
     args = ap.parse_args()
+    args.nn_moves = max(1, args.nn_moves)
 
     import torch
     import torch.distributed as dist

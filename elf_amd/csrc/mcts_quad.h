@@ -16,13 +16,22 @@
 
 namespace mcts {
 
+#ifndef ELFHIP_QUAD_TRAJ_LDS
+#define ELFHIP_QUAD_TRAJ_LDS 32   // trajectory steps kept in LDS (a build with 2 runs the tests through the deeper-steps path)
+#endif
+
 template <class G>
 struct QuadScratch {   // per 16-lane group
   uint16_t keys[G::MAXLEGAL], pos[G::MAXLEGAL], seq[G::MAXLEGAL];
   int rkey[G::MAXLEGAL];
   int table[G::MAXLEGAL <= 59 ? 64 : (G::MAXLEGAL <= 127 ? 128 : 272)];
   int leaf[MAXB], locked[MAXB];
+  // the batch's trajectories stay in LDS (nothing outside this launch reads them): the first QTD steps of each,
+  // deeper steps go to the arrays in memory that the split kernels use
+  int len[MAXB]; float val[MAXB];
+  uint16_t traj[MAXB][ELFHIP_QUAD_TRAJ_LDS];
 };
+constexpr int QTD = ELFHIP_QUAD_TRAJ_LDS;
 
 __device__ inline uint32_t gballot(bool p, int g) { return (uint32_t)(__ballot(p) >> (g * 16)) & 0xFFFFu; }
 template <class T>
@@ -168,14 +177,17 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
           }
           const uint32_t cmask = gballot(counted != 0, g);
           // the reference's own loop over the edges, in edge order, on values broadcast inside the group
-          for_each_k([&](auto kc) {
+          auto scan = [&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const float sk = rowbcast<k>(score);
             const float uk = rowbcast<k>(uq);
             const bool valid = go && base + k < ne;
             if (valid && (sk > best || bestj == 0x7FFFFFFF)) { best = sk; bestj = base + k; }
             if (valid && ((cmask >> k) & 1)) { total_uq += uk; total_cnt++; }
-          }, std::make_integer_sequence<int, 16>{});
+          };
+          for_each_k(scan, std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>{});
+          if (__any(go && ne - base > 8))   // most checkers nodes have at most eight edges
+            for_each_k(scan, std::integer_sequence<int, 8, 9, 10, 11, 12, 13, 14, 15>{});
           const int sel = (bestj >= base && bestj < base + 16) ? bestj - base : 0;
           const int cs = gbcast(cj, sel, lane), as = gbcast(aj, sel, lane);
           const float vs = gbcast(vloss, sel, lane);
@@ -205,13 +217,13 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
         }
         if (go) {
           if (o.vl > 0) tv.in_l[child] = bestvl + (float)o.vl;  // addVirtualLoss :246-264
-          tn[depth] = (uint16_t)node;
+          if (depth < QTD) S.traj[j][depth] = (uint16_t)node; else tn[depth] = (uint16_t)node;
         }
         __threadfence_block();
         if (go) { node = child; ++depth; h0 = n0; h_mq = n_mq; h_pq = n_pq; }
       }
       if (alive) {
-        d.traj_len[(size_t)tt * o.B + j] = depth;
+        S.len[j] = depth; S.val[j] = __uint_as_float(h0.w);   // the stopping node's V (rewritten below if it is evaluated now)
         rollouts += 1; depth_sum += (unsigned long long)depth;
         // requestEvaluation tree_search_node.h:169-179 (h0 is the header of the node the descent stopped at)
         const uint32_t meta = h0.x;
@@ -268,6 +280,7 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
         edge_sum += (unsigned long long)m;
       }
       if (ex) {
+        S.val[j] = value;
         for (int jj = gl; jj < m; jj += 16) {
           const int p = S.pos[jj];
           *(uint2*)(tv.ep.p + (size_t)(eb + jj) * EDGE_BYTES) = make_uint2(__float_as_uint(prior), (uint32_t)S.keys[p] | ((uint32_t)NOCHILD << 16));
@@ -283,14 +296,15 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
       bool first = alive; int count = 0;
       for (int k = 0; k < o.B; ++k) if (alive && S.leaf[k] == leaf) { if (k < j) first = false; ++count; }
       if (__any(first)) {
-        const float reward = first ? tv.V[leaf] : 0.f;
-        const int len = first ? d.traj_len[(size_t)tt * o.B + j] : 0;
+        const float reward = first ? S.val[j] : 0.f;
+        const int len = first ? S.len[j] : 0;
         const uint16_t* tn = d.traj_node + ((size_t)tt * o.B + j) * MAXD;
+        auto step_node = [&](int i) { return i < QTD ? (int)S.traj[j][i] : (int)tn[i]; };
         for (int i0 = 0; __any(i0 < len); i0 += 16) {
           const int i = i0 + gl;
           if (i < len) {
-            const int node = tn[i];
-            const int child = i + 1 < len ? (int)tn[i + 1] : leaf;
+            const int node = step_node(i);
+            const int child = i + 1 < len ? step_node(i + 1) : leaf;
             tv.visits[node] = tv.visits[node] + 1;
             uint4* st = (uint4*)(tv.in_r.p + (size_t)child * NODE_BYTES);   // {reward, num_visits, virtual_loss, -}
             const uint4 x = *st;

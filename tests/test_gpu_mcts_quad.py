@@ -2,7 +2,9 @@
 for run_uniform (ELFHIP_MCTS_QUAD=0 selects the latter): identical trees bit for bit - edges in iteration order, visit
 counts, rewards, priors, chosen moves, search statistics - over several moves with persistent trees, for the three
 checkers-family games, with a tree count that is not a multiple of four, and when arenas overflow (parked trees).
-The oracle comparisons of test_gpu_mcts.py / test_gpu_games_mcts.py run on the new kernel by default."""
+The oracle comparisons of test_gpu_mcts.py / test_gpu_mcts_games.py run on the new kernel by default.
+The kernel keeps the first 32 steps of a trajectory in LDS and deeper ones in memory; the deeper path was verified by
+running these files against a build with -DELFHIP_QUAD_TRAJ_LDS=2 (benchmarks/_build_prof_lib.sh): same results."""
 import numpy as np
 import pytest
 
