@@ -196,7 +196,7 @@ struct GameMcts : MctsBase {
   }
   int run_uniform() override {
     if (quad_enabled()) {   // four trees per wave (mcts_quad.h)
-      hipLaunchKernelGGL(quad_search_kernel<G>, dim3((d.n_trees + 3) / 4), dim3(64), 0, stream, d, o);
+      hipLaunchKernelGGL(quad_search_kernel<G>, dim3((d.n_trees + 3) / 4), dim3(64), quad_dynamic_lds<G>(o.B), stream, d, o);
       HIPCHECK(hipGetLastError());
       return ELFHIP_OK;
     }

@@ -20,18 +20,36 @@ namespace mcts {
 #define ELFHIP_QUAD_TRAJ_LDS 32   // trajectory steps kept in LDS (a build with 2 runs the tests through the deeper-steps path)
 #endif
 
+// LDS of one 16-lane group.  The arrays that depend on the batch size are carved out of dynamic shared memory (four
+// waves of four trees per SIMD only fit if a workgroup stays under 10 KB of LDS):
+//   fixed part (QuadScratch): the scratch of the hashtable order
+//   per slot j < B: leaf, locked, len, fresh (int), val (float), traj[QTD] (u16), st[W64] (u64)
+// The batch's trajectories stay in LDS (nothing outside this launch reads them): the first QTD steps of each, deeper
+// steps go to the arrays in memory that the split kernels use.  st = the game state of a leaf created by this batch's
+// own descent (fresh[j]): setEvaluation reads it back from here instead of from the node it was just stored to.
 template <class G>
-struct QuadScratch {   // per 16-lane group
+struct QuadScratch {
   uint16_t keys[G::MAXLEGAL], pos[G::MAXLEGAL], seq[G::MAXLEGAL];
   int rkey[G::MAXLEGAL];
   int table[G::MAXLEGAL <= 59 ? 64 : (G::MAXLEGAL <= 127 ? 128 : 272)];
-  int leaf[MAXB], locked[MAXB];
-  // the batch's trajectories stay in LDS (nothing outside this launch reads them): the first QTD steps of each,
-  // deeper steps go to the arrays in memory that the split kernels use
-  int len[MAXB]; float val[MAXB];
-  uint16_t traj[MAXB][ELFHIP_QUAD_TRAJ_LDS];
 };
 constexpr int QTD = ELFHIP_QUAD_TRAJ_LDS;
+template <class G>
+struct QuadSlots {
+  uint64_t* st; uint16_t* traj; int *leaf, *locked, *len, *fresh; float* val;
+  __host__ __device__ static size_t bytes(int B) {
+    const size_t b = (size_t)B * (G::W64 * 8 + QTD * 2 + 5 * 4);
+    return (b + 15) & ~(size_t)15;
+  }
+  __device__ void carve(char* p, int B) {
+    st = (uint64_t*)p; p += (size_t)B * G::W64 * 8;
+    leaf = (int*)p; p += B * 4; locked = (int*)p; p += B * 4; len = (int*)p; p += B * 4; fresh = (int*)p; p += B * 4;
+    val = (float*)p; p += B * 4;
+    traj = (uint16_t*)p;
+  }
+};
+template <class G>
+size_t quad_dynamic_lds(int B) { return 4 * QuadSlots<G>::bytes(B); }
 
 __device__ inline uint32_t gballot(bool p, int g) { return (uint32_t)(__ballot(p) >> (g * 16)) & 0xFFFFu; }
 template <class T>
@@ -96,11 +114,17 @@ __device__ inline void umap_order_group(bool run, const uint16_t* keys, int m, i
 template <class G>
 __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
   __shared__ QuadScratch<G> SS[4];
+  extern __shared__ __attribute__((aligned(16))) char q_dyn[];
+  __shared__ uint16_t s_order[G::NA];   // std::sort order of NA equal keys (the uniform policy's pi2response order)
   const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
+  for (int i = lane; i < G::NA; i += 64) s_order[i] = d.uniform_order[i];
+  stdorder::wave_sync();
   const int t = blockIdx.x * 4 + g;
   const bool exists = t < d.n_trees;
   const int tt = exists ? t : 0;
   QuadScratch<G>& S = SS[g];
+  QuadSlots<G> Q;
+  Q.carve(q_dyn + (size_t)g * QuadSlots<G>::bytes(o.B), o.B);
   int flags = exists ? d.t_flags[tt] : FLAG_INACTIVE;
   const bool entered = exists && flags == 0;          // overflowed / mismatched / inactive trees are parked
   TV tv = tree_view(d, tt);
@@ -116,6 +140,7 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
       uint16_t* tn = d.traj_node + ((size_t)tt * o.B + j) * MAXD;
       int node = 0, depth = 0;
       bool run = alive;
+      int fresh = 0;
       // The search is a chain of dependent memory round trips (four waves per SIMD do not hide them), so the chain is
       // kept short: only the root's header is loaded by itself.  A child's whole record comes with the edge
       // statistics that live in it (same 64-byte line), and the chosen child's header is handed to the next level
@@ -209,6 +234,7 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
             G::load(gstate(node), s);
             G::play(s, action);
             G::store(gstate(child), s);
+            G::store(Q.st + (size_t)j * G::W64, s); fresh = 1;
             tv.meta[child] = NOT_VISITED | META_STATE_SET;
             tv.ec[e] = (uint16_t)child;
             bestvl = 0.f;
@@ -217,30 +243,30 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
         }
         if (go) {
           if (o.vl > 0) tv.in_l[child] = bestvl + (float)o.vl;  // addVirtualLoss :246-264
-          if (depth < QTD) S.traj[j][depth] = (uint16_t)node; else tn[depth] = (uint16_t)node;
+          if (depth < QTD) Q.traj[j * QTD + depth] = (uint16_t)node; else tn[depth] = (uint16_t)node;
         }
         __threadfence_block();
         if (go) { node = child; ++depth; h0 = n0; h_mq = n_mq; h_pq = n_pq; }
       }
       if (alive) {
-        S.len[j] = depth; S.val[j] = __uint_as_float(h0.w);   // the stopping node's V (rewritten below if it is evaluated now)
+        Q.len[j] = depth; Q.val[j] = __uint_as_float(h0.w);   // the stopping node's V (rewritten below if it is evaluated now)
         rollouts += 1; depth_sum += (unsigned long long)depth;
         // requestEvaluation tree_search_node.h:169-179 (h0 is the header of the node the descent stopped at)
         const uint32_t meta = h0.x;
         const int lock = (meta & 0xFF) == NOT_VISITED;
         if (lock) tv.meta[node] = (meta & ~0xFFu) | EVAL_REQUESTED;
-        S.leaf[j] = node; S.locked[j] = lock;
+        Q.leaf[j] = node; Q.locked[j] = lock; Q.fresh[j] = fresh;
       }
       __threadfence_block();
     }
     stdorder::wave_sync();
     // ---- setEvaluation of the locked leaves, uniform evaluator (pi = 1 / NA, V = 0) ----
     for (int j = 0; j < o.B; ++j) {
-      const bool ex = alive && S.locked[j] != 0;
+      const bool ex = alive && Q.locked[j] != 0;
       if (!__any(ex)) continue;
-      const int leaf = ex ? S.leaf[j] : 0;
+      const int leaf = ex ? Q.leaf[j] : 0;
       typename G::S s;
-      G::load(gstate(leaf), s);
+      if (ex && Q.fresh[j]) G::load(Q.st + (size_t)j * G::W64, s); else G::load(gstate(leaf), s);
       uint64_t mk[G::MW]; bool terminal, flip; float value;
       G::eval(s, mk, terminal, flip, value);   // pre_evaluate (actor :198-218)
       if (!terminal) value = 0.0f;
@@ -253,7 +279,7 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
       for (int c = 0; c < G::NA; c += 16) {
         const int i = c + gl;
         const bool in = i < G::NA;
-        const int a = in ? (int)d.uniform_order[i] : 0;
+        const int a = in ? (int)s_order[i] : 0;
         uint64_t word = 0;
 #pragma unroll
         for (int q = 0; q < G::MW; ++q) word = (a >> 6) == q ? mk[q] : word;
@@ -280,7 +306,7 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
         edge_sum += (unsigned long long)m;
       }
       if (ex) {
-        S.val[j] = value;
+        Q.val[j] = value;
         for (int jj = gl; jj < m; jj += 16) {
           const int p = S.pos[jj];
           *(uint2*)(tv.ep.p + (size_t)(eb + jj) * EDGE_BYTES) = make_uint2(__float_as_uint(prior), (uint32_t)S.keys[p] | ((uint32_t)NOCHILD << 16));
@@ -292,14 +318,14 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
     }
     // ---- backup (tree_search.h:291-305 + updateEdgeStats tree_search_node.h:267-292) ----
     for (int j = 0; j < o.B; ++j) {
-      const int leaf = alive ? S.leaf[j] : -1;
+      const int leaf = alive ? Q.leaf[j] : -1;
       bool first = alive; int count = 0;
-      for (int k = 0; k < o.B; ++k) if (alive && S.leaf[k] == leaf) { if (k < j) first = false; ++count; }
+      for (int k = 0; k < o.B; ++k) if (alive && Q.leaf[k] == leaf) { if (k < j) first = false; ++count; }
       if (__any(first)) {
-        const float reward = first ? S.val[j] : 0.f;
-        const int len = first ? S.len[j] : 0;
+        const float reward = first ? Q.val[j] : 0.f;
+        const int len = first ? Q.len[j] : 0;
         const uint16_t* tn = d.traj_node + ((size_t)tt * o.B + j) * MAXD;
-        auto step_node = [&](int i) { return i < QTD ? (int)S.traj[j][i] : (int)tn[i]; };
+        auto step_node = [&](int i) { return i < QTD ? (int)Q.traj[j * QTD + i] : (int)tn[i]; };
         for (int i0 = 0; __any(i0 < len); i0 += 16) {
           const int i = i0 + gl;
           if (i < len) {
