@@ -563,6 +563,7 @@ mcts_policy_only_kernel(TreeDev d, const uint8_t* __restrict__ which, int16_t* _
 static __global__ void __launch_bounds__(64) mcts_advance_kernel(TreeDev d, const int16_t* __restrict__ actions, int first_tree) {
   extern __shared__ uint16_t s_map[];  // new index -> old index  [max_nodes]
   __shared__ int s_child;
+  __shared__ int s_eb[64], s_off[65];
   const int t = first_tree + blockIdx.x, lane = threadIdx.x;
   const int a = actions[t];
   if (a < 0) return;
@@ -581,7 +582,7 @@ static __global__ void __launch_bounds__(64) mcts_advance_kernel(TreeDev d, cons
     if (lane == 0) reset_tree(d, t);
     return;
   }
-  // a node record moves as its four 16-byte quarters (parent re-indexed); lanes 0..3 of a group take one each
+  // a node record moves as its 16-byte quarters (parent re-indexed) plus its game state
   auto copy_node = [&](int dst, int src, int parent) {
     const uint4* sr = (const uint4*)(o.meta.p + (size_t)src * NODE_BYTES);
     uint4* dr = (uint4*)(n.meta.p + (size_t)dst * NODE_BYTES);
@@ -591,31 +592,55 @@ static __global__ void __launch_bounds__(64) mcts_advance_kernel(TreeDev d, cons
   };
   if (lane == 0) { copy_node(0, c, -1); s_map[0] = (uint16_t)c; }
   __syncthreads();
+  // Breadth first, 64 nodes of the frontier at a time: their headers in one round trip (a lane per node), their
+  // edges flattened over the lanes (an edge finds its node by a search in the prefix sums of the edge counts), the
+  // children numbered in (parent, edge) order - the numbering of a node-by-node walk, at a few memory round trips
+  // per 64 nodes instead of two per node.
   int count = 1, ecount = 0;
-  for (int i = 0; i < count; ++i) {
-    const int old = s_map[i];
-    const uint32_t m = o.meta[old];
-    const int ne = (m & 0xFF) == VISITED ? (int)(m >> 16) : 0;
-    const int eb = (int)o.ebase[old];
-    if (lane == 0) n.ebase[i] = (uint32_t)ecount;
-    for (int base = 0; base < ne; base += 64) {
-      const int j = base + lane; const bool ok = j < ne;
+  for (int lo = 0, hi = 0; lo < count; lo = hi) {
+    hi = count < lo + 64 ? count : lo + 64;
+    const int i = lo + lane;
+    int ne = 0, eb = 0;
+    if (i < hi) {
+      const int old = s_map[i];
+      const uint2 h = *(const uint2*)(o.meta.p + (size_t)old * NODE_BYTES);   // meta, ebase
+      ne = (h.x & 0xFF) == VISITED ? (int)(h.x >> 16) : 0;
+      eb = (int)h.y;
+    }
+    int off = ne;   // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) { const int v = __shfl_up(off, sft); if (lane >= sft) off += v; }
+    const int total = __shfl(off, 63);
+    off -= ne;
+    if (i < hi) n.ebase[i] = (uint32_t)(ecount + off);
+    s_eb[lane] = eb; s_off[lane] = off;
+    if (lane == 0) s_off[64] = total;
+    __syncthreads();
+    int added = 0;
+    for (int f0 = 0; f0 < total; f0 += 64) {
+      const int f = f0 + lane; const bool ok = f < total;
+      int k = 0;
+      if (ok) {   // the last node whose first edge is at or before f (nodes without edges have equal offsets: skipped)
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) if (k + step < 64 && s_off[k + step] <= f) k += step;
+      }
       uint2 e = make_uint2(0u, 0u);
       int oc = NOCHILD;
-      if (ok) { e = *(const uint2*)(o.ep.p + (size_t)(eb + j) * EDGE_BYTES); oc = (int)(e.y >> 16); }
+      if (ok) { e = *(const uint2*)(o.ep.p + (size_t)(s_eb[k] + f - s_off[k]) * EDGE_BYTES); oc = (int)(e.y >> 16); }
       const unsigned long long has = __ballot(ok && oc != NOCHILD);
       if (ok) {
         if (oc != NOCHILD) {
-          const int ni = count + __popcll(has & ((1ull << lane) - 1));
+          const int ni = count + added + __popcll(has & ((1ull << lane) - 1));
           s_map[ni] = (uint16_t)oc;
-          copy_node(ni, oc, i);
+          copy_node(ni, oc, lo + k);
           e.y = (e.y & 0xFFFFu) | ((uint32_t)ni << 16);
         }
-        *(uint2*)(n.ep.p + (size_t)(ecount + j) * EDGE_BYTES) = e;
+        *(uint2*)(n.ep.p + (size_t)(ecount + f) * EDGE_BYTES) = e;
       }
-      count += __popcll(has);
+      added += __popcll(has);
     }
-    ecount += ne;
+    count += added;
+    ecount += total;
     __syncthreads();
   }
   if (lane == 0) { d.t_arena[t] = spare; d.spare_arena[blockIdx.x] = arena; d.t_nnodes[t] = count; d.t_nedges[t] = ecount; }
