@@ -159,8 +159,16 @@ __device__ inline void go_grow(uint32_t (&F)[GN], const uint32_t (&M)[GN], const
 }
 
 // grow F (subset of M) to the complete M-components it touches; every lane of the wave takes part
+// The seeds run straight up their columns first (one instruction per row): the first pass sweeps DOWN, so whatever a
+// seed reaches by going up a column and then sideways or down is found in that pass already instead of in the next.
+__device__ inline void go_seed_up(uint32_t (&F)[GN], const uint32_t (&M)[GN]) {
+#pragma unroll
+  for (int i = GN - 2; i >= 0; --i) F[i] |= F[i + 1] & M[i];
+}
+
 __device__ inline void go_fill_complete(uint32_t (&F)[GN], const uint32_t (&M)[GN]) {
   PROF_INC(20, 1);
+  go_seed_up(F, M);
   for (;;) {
     uint32_t pend; int nl;
     PROF_INC(21, 1);
@@ -184,6 +192,7 @@ __device__ inline void go_group_status(GoS& s, uint32_t (&F)[GN], const uint32_t
   bool fin = false, noop = false;
   int nlib = 0;
   PROF_INC(20, 1);
+  go_seed_up(F, M);
   for (;;) {
     uint32_t pend;
     PROF_INC(21, 1);
