@@ -160,7 +160,8 @@ __device__ inline void go_grow(uint32_t (&F)[GN], const uint32_t (&M)[GN], const
 
 // grow F (subset of M) to the complete M-components it touches; every lane of the wave takes part
 // The seeds run straight up their columns first (one instruction per row): the first pass sweeps DOWN, so whatever a
-// seed reaches by going up a column and then sideways or down is found in that pass already instead of in the next.
+// seed reaches by going up a column and then sideways or down is found in that pass already instead of in the next
+// (richer pre-passes - a sideways step per row, or the exact row flood on the way up - cost more than they save).
 __device__ inline void go_seed_up(uint32_t (&F)[GN], const uint32_t (&M)[GN]) {
 #pragma unroll
   for (int i = GN - 2; i >= 0; --i) F[i] |= F[i + 1] & M[i];
