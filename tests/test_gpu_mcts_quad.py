@@ -72,3 +72,24 @@ def test_quad_kernel_parks_trees_like_the_wave_kernel(monkeypatch):
         b = _run(AMERICAN, 9, 3, opts, False, monkeypatch)
         _same(a, b)
         assert a[-1]["flags"].any()
+
+
+def test_configs2_full_size_same_trees_and_invariants(monkeypatch):
+    """BASELINE.json configs[2] at its full size (16,384 games, 256 rollouts per move, batch 8, virtual loss 1): the two
+    kernels agree on every tree, nothing is parked, and the counts add up (every rollout of a move passes through one
+    root edge except the one that evaluates a fresh root and the duplicates of a batch, which are backed up once)."""
+    from elf_amd.boards import AMERICAN
+    n, R = 16384, 256
+    opts = dict(num_rollouts_per_thread=R, num_rollouts_per_batch=8, virtual_loss=1, c_puct=1.5)
+    a = _run(AMERICAN, n, 2, opts, True, monkeypatch, start_plies=10)
+    b = _run(AMERICAN, n, 2, opts, False, monkeypatch, start_plies=10)
+    _same(a, b)
+    assert a[-1]["stats"]["rollouts"] == n * R * 2
+    for mv in a:
+        assert not mv["flags"].any() and mv["ok"].all()
+        assert np.array_equal(mv["edge_visits"].sum(1), mv["total_visits"])
+        assert np.array_equal(mv["policy_visits"].sum(1), mv["total_visits"])
+        assert (mv["n_edges"] > 0).all() and (mv["best"] >= 0).all()
+    # fresh trees: the first rollout evaluates the root; a batch's duplicate leaves are backed up once (tree_search.h:291-305)
+    assert (a[0]["total_visits"] <= R - 1).all() and (a[0]["total_visits"] > R // 2).all()
+    assert (a[1]["total_visits"] > R // 2).all()
