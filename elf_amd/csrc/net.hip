@@ -43,6 +43,10 @@ __device__ inline uint32_t pack_bf16(float lo, float hi) {
 // nn.ReLU, or nn.LeakyReLU(slope) when the model was built with --leaky_relu (model_american_checkers.py:51,204: 0.1)
 __device__ inline float act_relu(float v, float slope) { return slope == 0.f ? fmaxf(v, 0.f) : fmaxf(v, v * slope); }
 
+#ifndef ELFHIP_NET_NBW8
+#define ELFHIP_NET_NBW8 6
+#endif
+constexpr int NBW8 = ELFHIP_NET_NBW8;   // 8x8 boards per workgroup of the board kernel (COUT <= 128)
 constexpr int KC = 32;        // input channels per K step
 constexpr int LROW = 40;      // LDS row stride in bf16 (32 data + 8 pad = 80 B)
 constexpr int BP = 128;       // positions per workgroup
@@ -1152,7 +1156,13 @@ struct NetImpl {
   template <int COUT>
   int conv_board(const uint16_t* x, const ConvW& c, const uint16_t* res, uint16_t* out, uint16_t* lo, int lo_in, int B, int relu) {   // 1: not this shape
     if (cfg.board == 19) return launch_board<COUT, 19, 1>(x, c, res, out, lo, lo_in, B, relu);
-    if (cfg.board == 8) return launch_board<COUT, 8, 4>(x, c, res, out, lo, lo_in, B, relu);
+    // 8x8: six boards per workgroup while the accumulators allow it (a wave tile of COUT/2 x 96 positions, the Go
+    // tile's shape: each weight fragment feeds six MFMAs and a board's share of the weight stream is a sixth), four
+    // boards for the wide shapes
+    if (cfg.board == 8) {
+      if constexpr (COUT <= 128) return launch_board<COUT, 8, NBW8>(x, c, res, out, lo, lo_in, B, relu);
+      else return launch_board<COUT, 8, 4>(x, c, res, out, lo, lo_in, B, relu);
+    }
     return 1;
   }
   // rows per chunk plane of the board kernel's chunk-major activations (0: the generic kernels' NHWC).  Fixed per
