@@ -238,13 +238,14 @@ __device__ inline void go_place(GoS& s, bool act, uint32_t r, uint32_t bit, cons
   uint32_t ST[GN];
   ROWS(i) ST[i] = (uint32_t)i == r ? bit : 0u;
   // ---- captures: opponent groups in atari next to the stone (their one liberty is this point) ----
-  bool own_at_nbr = false;  // an own group in atari touches the point: it merges and must be rewritten
+  uint32_t own_at = 0;      // own stones in atari next to the point
   ROWS(i) {
     const uint32_t s0 = ST[i], su = i + 1 < GN ? ST[i + 1 < GN ? i + 1 : 0] : 0u, sd = i > 0 ? ST[i > 0 ? i - 1 : 0] : 0u;
     const uint32_t nbr = ((s0 << 1) | (s0 >> 1) | su | sd) & FULL;
     F[i] = nbr & s.Q[i] & s.AT[i];
-    own_at_nbr = own_at_nbr || (nbr & s.P[i] & s.AT[i]) != 0;
+    own_at |= nbr & s.P[i] & s.AT[i];
   }
+  const bool own_at_nbr = own_at != 0;  // an own group in atari touches the point: it merges and must be rewritten
   const bool any_cap = go_any_rows(F);
   PROF_ADD(0);
   if (any_cap) {
@@ -289,6 +290,7 @@ __device__ inline void go_place(GoS& s, bool act, uint32_t r, uint32_t bit, cons
   PROF_ADD(3);
   // ---- the (up to four) opponent groups that lost this liberty.  None of them carries an AT bit:
   //      a neighbour in atari was just captured. ----
+  const bool crowded = !__any(act && s.ply < 48);
 #pragma unroll 1
   for (int d = 0; d < 4; ++d) {  // 0 up, 1 down, 2 left, 3 right
     // the neighbouring point in direction d: the stone's row set moved up / down a row or left / right a column
@@ -297,7 +299,9 @@ __device__ inline void go_place(GoS& s, bool act, uint32_t r, uint32_t bit, cons
     else if (d == 1) { ROWS(i) F[i] = (i > 0 ? ST[i > 0 ? i - 1 : 0] : 0u) & s.Q[i]; }
     else if (d == 2) { ROWS(i) F[i] = (ST[i] >> 1) & s.Q[i]; }
     else { ROWS(i) F[i] = (ST[i] << 1) & s.Q[i]; }   // Q has no bits above column 18
-    const bool any = go_any_rows(F);
+    // once the board has filled up some lane of the wave always has an opponent stone in this direction: the test
+    // (19 ORs and a ballot) is only made while every lane is early in its game
+    const bool any = crowded || go_any_rows(F);
     PROF_ADD(0);
     if (!any) continue;
     PROF_INC(13 + d, 1);
