@@ -135,6 +135,8 @@ __global__ void __launch_bounds__(256)
 am_playout_kernel(uint64_t* __restrict__ w, uint64_t* __restrict__ hist, uint32_t* __restrict__ hmeta, int n,
                   int nply, uint64_t seed, uint64_t first_id, uint64_t step_base,
                   unsigned long long* __restrict__ moves_out) {
+  __shared__ uint32_t s_mod[2][64 + 1];   // legal moves of a position: at most 12 pieces x 4
+  elf_modtab_fill<64>(s_mod);
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long moves = 0;
   if (b < n) {
@@ -147,7 +149,7 @@ am_playout_kernel(uint64_t* __restrict__ w, uint64_t* __restrict__ hist, uint32_
       if (total == 0 || am_ply(s) >= AM_MAX_PLY) { am_clear(s); continue; }
       total = am_apply_repeat_rule(s, fam, total);
       uint64_t r = elf_splitmix64(key + (uint64_t)step);
-      int kk = (int)elf_mod_u64_small(r, (uint32_t)total);
+      int kk = (int)(total <= 64 ? elf_mod_u64_tab<64>(r, (uint32_t)total, s_mod) : elf_mod_u64_small(r, (uint32_t)total));
       // k-th legal move in ascending action index == k-th set bit over fam[0..7]
       int t = 0; uint64_t sel = 0; bool found = false;
 #pragma unroll
@@ -157,8 +159,7 @@ am_playout_kernel(uint64_t* __restrict__ w, uint64_t* __restrict__ hist, uint32_
         if (here) { t = q; sel = fam[q]; found = true; }
         if (!found) kk -= c;
       }
-      for (int j = 0; j < kk; ++j) sel &= sel - 1;
-      int i = __ffsll((long long)sel) - 1;
+      int i = (int)elf_kth_bit64(sel, kk);
       uint64_t valid = (t & 1) ? ((t >= 4) ? V10 : V5) : ((t >= 4) ? V8 : V4);
       int base = 0;
 #pragma unroll

@@ -34,6 +34,48 @@ __device__ inline uint32_t elf_mod_u64_small(uint64_t r, uint32_t n) {
   return (a * p32 + b) % n;  // a*p32 < 2^32 because a,p32 < 2^16
 }
 
+#ifdef __HIPCC__
+// The same r mod n through per-n reciprocals kept in LDS (the playout kernels draw one move per board and ply):
+// tab[0][n] = floor((2^32 - 1) / n), tab[1][n] = 2^32 mod n for n = 1..NMAX; three multiply-high reductions
+// instead of five 32-bit divisions.  elf_modtab_fill is called by every thread of the block (it synchronises).
+template <int NMAX>
+__device__ inline void elf_modtab_fill(uint32_t (&tab)[2][NMAX + 1]) {
+  for (int n = threadIdx.x + 1; n <= NMAX; n += blockDim.x) {
+    tab[0][n] = 0xFFFFFFFFu / (uint32_t)n;
+    tab[1][n] = ((0xFFFFFFFFu % (uint32_t)n) + 1u) % (uint32_t)n;
+  }
+  __syncthreads();
+}
+// x mod n with rc = floor((2^32 - 1) / n): the estimate mulhi(x, rc) is the quotient or one less
+__device__ inline uint32_t elf_mod_small(uint32_t x, uint32_t n, uint32_t rc) {
+  const uint32_t r = x - __umulhi(x, rc) * n;
+  return r >= n ? r - n : r;
+}
+template <int NMAX>
+__device__ inline uint32_t elf_mod_u64_tab(uint64_t r, uint32_t n, const uint32_t (&tab)[2][NMAX + 1]) {
+  const uint32_t rc = tab[0][n], p32 = tab[1][n];
+  const uint32_t hi = elf_mod_small((uint32_t)(r >> 32), n, rc), lo = elf_mod_small((uint32_t)r, n, rc);
+  return elf_mod_small(hi * p32 + lo, n, rc);   // hi * p32 + lo < 2^32: both factors are below n <= NMAX < 2^15
+}
+// position of the k-th (from 0) set bit, k < popcount(x): halving steps, no loop
+__device__ inline uint32_t elf_kth_bit32(uint32_t x, int k) {
+  uint32_t pos = 0;
+#pragma unroll
+  for (int w = 16; w >= 1; w >>= 1) {
+    const int c = __popc(x & ((1u << w) - 1u));
+    const bool hi = k >= c;
+    k -= hi ? c : 0; x = hi ? x >> w : x; pos += hi ? (uint32_t)w : 0u;
+  }
+  return pos;
+}
+__device__ inline uint32_t elf_kth_bit64(uint64_t x, int k) {
+  const uint32_t lo = (uint32_t)x;
+  const int c = __popc(lo);
+  const bool hi = k >= c;
+  return elf_kth_bit32(hi ? (uint32_t)(x >> 32) : lo, hi ? k - c : k) + (hi ? 32u : 0u);
+}
+#endif
+
 // Abstract slab of boards; one subclass per game (american.hip, go.hip, ...).
 struct BoardSlab {
   int game = 0, n = 0, device = 0;

@@ -88,6 +88,8 @@ ru_evaluate_kernel(const uint64_t* __restrict__ w, float* __restrict__ v, int n)
 __global__ void __launch_bounds__(256)
 ru_playout_kernel(uint64_t* __restrict__ w, int n, int nply, uint64_t seed, uint64_t first_id, uint64_t step_base,
                   unsigned long long* __restrict__ moves_out) {
+  __shared__ uint32_t s_mod[2][128 + 1];
+  elf_modtab_fill<128>(s_mod);
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long moves = 0;
   if (b < n) {
@@ -99,7 +101,7 @@ ru_playout_kernel(uint64_t* __restrict__ w, int n, int nply, uint64_t seed, uint
       int total = ru_count(m);
       if (total == 0 || ru_ply(s.w4) >= RU_MAX_PLY) { ru_clear(s); continue; }
       uint64_t r = elf_splitmix64(key + (uint64_t)step);
-      int kk = (int)elf_mod_u64_small(r, (uint32_t)total);
+      int kk = (int)(total <= 128 ? elf_mod_u64_tab<128>(r, (uint32_t)total, s_mod) : elf_mod_u64_small(r, (uint32_t)total));
       ru_play(s, ru_kth(m, kk));
       ++moves;
     }

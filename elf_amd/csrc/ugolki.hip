@@ -93,6 +93,8 @@ __global__ void ug_evaluate_kernel(const uint64_t* __restrict__ w, float* __rest
 __global__ void __launch_bounds__(256)
 ug_playout_kernel(uint64_t* __restrict__ w, int n, int nply, uint64_t seed, uint64_t first_id, uint64_t step_base,
                   unsigned long long* __restrict__ moves_out) {
+  __shared__ uint32_t s_mod[2][128 + 1];
+  elf_modtab_fill<128>(s_mod);
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long moves = 0;
   if (b < n) {
@@ -104,7 +106,7 @@ ug_playout_kernel(uint64_t* __restrict__ w, int n, int nply, uint64_t seed, uint
       int total = ug_count(fam, pass);
       if (total == 0 || ug_over(s) || ug_ply(s) >= UG_MAX_PLY) { ug_clear(s); continue; }
       uint64_t r = elf_splitmix64(key + (uint64_t)step);
-      int kk = (int)elf_mod_u64_small(r, (uint32_t)total);
+      int kk = (int)(total <= 128 ? elf_mod_u64_tab<128>(r, (uint32_t)total, s_mod) : elf_mod_u64_small(r, (uint32_t)total));
       // k-th legal move in ascending action index == k-th set bit over fam[0..7], then pass
       int g = -1; uint64_t sel = 0; bool found = false;
 #pragma unroll
@@ -116,8 +118,7 @@ ug_playout_kernel(uint64_t* __restrict__ w, int n, int nply, uint64_t seed, uint
       }
       int i = 0;
       if (found) {
-        for (int j = 0; j < kk; ++j) sel &= sel - 1;
-        i = __ffsll((long long)sel) - 1;
+        i = (int)elf_kth_bit64(sel, kk);
       }
       ug_play(s, g, i);
       ++moves;
