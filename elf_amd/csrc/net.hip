@@ -303,7 +303,13 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
   // the rest to waves 0-3 only.  Those request at the top of a stage pair and then wait at the barrier for
   // their partners (which request mid-pair, with the matrix pipe shared, and are the critical path): the
   // extra pieces cost them slack, not time.
+#if defined(CONV_X_HALFW)   // timing experiments only (outputs wrong): 8 of the 14 weight pieces per stage / none at all
+  auto apiece = [&](int i) { return i == 0 ? wave : AI; };
+#elif defined(CONV_X_NOW)
+  auto apiece = [&](int i) { return AI; };
+#else
   auto apiece = [&](int i) { return i == 0 ? wave : (wave < 4 ? 4 + 4 * i + wave : AI); };
+#endif
   uint32_t aoff[NAW];
 #pragma unroll
   for (int i = 0; i < NAW; ++i) aoff[i] = (uint32_t)((apiece(i) * 16 + r16) * KC + q * 8) * 2u;   // piece = 1 KiB contiguous
@@ -327,7 +333,11 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
       const uint32_t ch = slot - row * 5u;
       row = min(row, (uint32_t)(rows_left - 1));
       const uint32_t off = (row * KC + (ch == 4 ? 0 : ch) * 8) * 2u;
+#ifdef CONV_X_HALFX   // timing experiment only (outputs wrong): every other activation piece
+      if (j < XI && !(i & 1))
+#else
       if (j < XI)
+#endif
         lds_dma16(src + off, sX + buf * XBYTES + j * 1024);
     }
   };
@@ -347,7 +357,12 @@ conv3x3_board_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict_
   int nA = 0;                                   // pieces this wave issues per weight slice / activation chunk
 #pragma unroll
   for (int i = 0; i < NAW; ++i) nA += apiece(i) < AI ? 1 : 0;
+#ifdef CONV_X_HALFX
+  int nX = 0;
+  for (int i = 0; i < NXW; i += 2) nX += wave + 8 * i < XI ? 1 : 0;
+#else
   const int nX = (XI - wave + 7) / 8;
+#endif
   const int total = nmine * nstage;    // stages of all this workgroup's board groups
   // Weight slices are requested in global stage order; the slice of global stage t lives in ring slot
   // t % RING (tracked incrementally: it_* describe the next stage to request).
