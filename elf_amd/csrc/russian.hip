@@ -89,24 +89,41 @@ __global__ void __launch_bounds__(256)
 ru_playout_kernel(uint64_t* __restrict__ w, int n, int nply, uint64_t seed, uint64_t first_id, uint64_t step_base,
                   unsigned long long* __restrict__ moves_out) {
   __shared__ uint32_t s_mod[2][128 + 1];
+  __shared__ uint16_t s_act[RU_ACTIONS];
+  for (int i = threadIdx.x; i < RU_ACTIONS; i += blockDim.x) s_act[i] = c_ru_act.ft[i];
   elf_modtab_fill<128>(s_mod);
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long moves = 0;
+#ifdef RU_PROF
+  for (int k = 0; k < 16; ++k) s_ru_prof[k][threadIdx.x] = 0;
+#endif
   if (b < n) {
     Ru s; ru_load(w, n, b, s);
     const uint64_t key = seed + (first_id + (uint64_t)b) * ELF_GOLDEN + step_base;
     for (int step = 0; step < nply; ++step) {
       uint64_t m[5];
+      RPROF_T0;
       ru_moves(s, m);
+      RPROF_ADD(5);
       int total = ru_count(m);
       if (total == 0 || ru_ply(s.w4) >= RU_MAX_PLY) { ru_clear(s); continue; }
       uint64_t r = elf_splitmix64(key + (uint64_t)step);
       int kk = (int)(total <= 128 ? elf_mod_u64_tab<128>(r, (uint32_t)total, s_mod) : elf_mod_u64_small(r, (uint32_t)total));
-      ru_play(s, ru_kth(m, kk));
+      const int a = ru_kth(m, kk);
+      RPROF_ADD(6);
+      ru_play(s, a, s_act);
+      RPROF_ADD(7);
       ++moves;
     }
     ru_store(w, n, b, s);
   }
+#ifdef RU_PROF
+  for (int k = 0; k < 16; ++k) {
+    unsigned long long v = s_ru_prof[k][threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) { unsigned long long u = __shfl_xor(v, o); v = u > v ? u : v; }
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_ru_prof[k], v);
+  }
+#endif
   if (moves_out) {
     for (int o = 32; o > 0; o >>= 1) moves += __shfl_down(moves, o);
     if ((threadIdx.x & 63) == 0) atomicAdd(moves_out, moves);
@@ -228,3 +245,11 @@ struct RussianSlab : BoardSlab {
 }  // namespace
 
 BoardSlab* elfhip_make_russian() { return new RussianSlab(); }
+
+#ifdef RU_PROF
+extern "C" int elfhip_debug_ru_prof(unsigned long long* h_out16, int reset) {
+  if (h_out16 && hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(rudev::g_ru_prof), 16 * 8) != hipSuccess) return -2;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rudev::g_ru_prof), z, 16 * 8) != hipSuccess) return -2; }
+  return 0;
+}
+#endif
