@@ -134,7 +134,13 @@ __device__ inline uint32_t kth_bit(uint32_t x, int k) {
 }
 
 // Random-legal playouts: nply steps per launch with the board in registers.
-__global__ void __launch_bounds__(64)
+#ifndef GO_PLAYOUT_BLOCK
+#define GO_PLAYOUT_BLOCK 64   // occupancy experiments only (benchmarks/_build_prof_lib.sh GO_PLAYOUT_BLOCK=256)
+#endif
+#ifdef GO_PLAYOUT_WAVES
+__attribute__((amdgpu_waves_per_eu(GO_PLAYOUT_WAVES, GO_PLAYOUT_WAVES)))
+#endif
+__global__ void __launch_bounds__(GO_PLAYOUT_BLOCK)
 go_playout_kernel(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t seed, uint64_t first_id,
                   uint64_t step_base, unsigned long long* __restrict__ moves_out) {
   __shared__ uint64_t z[GO_ZWORDS];
@@ -359,7 +365,7 @@ struct GoSlab : BoardSlab {
     return ELFHIP_OK;
   }
   int playout(int nply, uint64_t seed, uint64_t first_id, unsigned long long* d_moves) override {
-    hipLaunchKernelGGL(go_playout_kernel, dim3(grid()), dim3(64), 0, stream, d, gz, nply, seed, first_id,
+    hipLaunchKernelGGL(go_playout_kernel, dim3((n + GO_PLAYOUT_BLOCK - 1) / GO_PLAYOUT_BLOCK), dim3(GO_PLAYOUT_BLOCK), 0, stream, d, gz, nply, seed, first_id,
                        step_counter, d_moves);
     HIPCHECK(hipGetLastError());
     step_counter += (uint64_t)nply;
