@@ -517,3 +517,11 @@ int elfhip_mcts_stats(elfhip_mcts* h, unsigned long long* h_stats4, int32_t* d_f
 }
 
 }  // extern "C"
+
+#ifdef QUAD_PROF
+extern "C" int elfhip_debug_quad_prof(unsigned long long* h_out8, int reset) {
+  if (h_out8 && hipMemcpyFromSymbol(h_out8, HIP_SYMBOL(mcts::g_quad_prof), 64) != hipSuccess) return -2;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mcts::g_quad_prof), z, 64) != hipSuccess) return -2; }
+  return 0;
+}
+#endif

@@ -16,6 +16,16 @@
 
 namespace mcts {
 
+#ifdef QUAD_PROF
+// timing-only instrumentation (never in the product build; benchmarks/_prof_quad.py): wave cycles per phase
+static __device__ unsigned long long g_quad_prof[8];
+#define QPROF_T0 unsigned long long _q0 = clock64()
+#define QPROF_ADD(k) do { unsigned long long _q1 = clock64(); qprof[k] += _q1 - _q0; _q0 = _q1; } while (0)
+#else
+#define QPROF_T0
+#define QPROF_ADD(k)
+#endif
+
 #ifndef ELFHIP_QUAD_TRAJ_LDS
 #define ELFHIP_QUAD_TRAJ_LDS 32   // trajectory steps kept in LDS (a build with 2 runs the tests through the deeper-steps path)
 #endif
@@ -131,6 +141,10 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
   int nn = d.t_nnodes[tt], ne_cnt = d.t_nedges[tt];
   unsigned long long rollouts = 0, evals = 0, depth_sum = 0, edge_sum = 0;
   const int nbatch = (o.R + o.B - 1) / o.B;
+#ifdef QUAD_PROF
+  unsigned long long qprof[4] = {0, 0, 0, 0};
+#endif
+  QPROF_T0;
   auto gstate = [&](int node) { return (uint64_t*)(tv.state + (size_t)node * (2 * G::W64)); };
   for (int batch = 0; batch < nbatch; ++batch) {
     const bool alive = entered && flags == 0;         // as the one-tree kernel: a batch that parks the tree is its last
@@ -260,6 +274,7 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
       __threadfence_block();
     }
     stdorder::wave_sync();
+    QPROF_ADD(0);
     // ---- setEvaluation of the locked leaves, uniform evaluator (pi = 1 / NA, V = 0) ----
     for (int j = 0; j < o.B; ++j) {
       const bool ex = alive && Q.locked[j] != 0;
@@ -316,6 +331,7 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
       }
       stdorder::wave_sync();
     }
+    QPROF_ADD(1);
     // ---- backup (tree_search.h:291-305 + updateEdgeStats tree_search_node.h:267-292) ----
     for (int j = 0; j < o.B; ++j) {
       const int leaf = alive ? Q.leaf[j] : -1;
@@ -341,7 +357,11 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
       }
       stdorder::wave_sync();   // trajectories (which share the nodes near the root) stay in order
     }
+    QPROF_ADD(2);
   }
+#ifdef QUAD_PROF
+  if (lane == 0) for (int k = 0; k < 3; ++k) atomicAdd(&g_quad_prof[k], qprof[k]);
+#endif
   if (entered && gl == 0) {
     d.t_nnodes[tt] = nn; d.t_nedges[tt] = ne_cnt; d.t_flags[tt] = flags;
     if (rollouts) atomicAdd(&d.stats[0], rollouts);
