@@ -89,8 +89,8 @@ __global__ void __launch_bounds__(256)
 ru_playout_kernel(uint64_t* __restrict__ w, int n, int nply, uint64_t seed, uint64_t first_id, uint64_t step_base,
                   unsigned long long* __restrict__ moves_out) {
   __shared__ uint32_t s_mod[2][128 + 1];
-  __shared__ uint16_t s_act[RU_ACTIONS];
-  for (int i = threadIdx.x; i < RU_ACTIONS; i += blockDim.x) s_act[i] = c_ru_act.ft[i];
+  __shared__ uint2 s_act[RU_ACTIONS];
+  for (int i = threadIdx.x; i < RU_ACTIONS; i += blockDim.x) s_act[i] = c_ru_act.e[i];
   elf_modtab_fill<128>(s_mod);
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long moves = 0;
@@ -98,7 +98,8 @@ ru_playout_kernel(uint64_t* __restrict__ w, int n, int nply, uint64_t seed, uint
   for (int k = 0; k < 16; ++k) s_ru_prof[k][threadIdx.x] = 0;
 #endif
   if (b < n) {
-    Ru s; ru_load(w, n, b, s);
+    Ru s64; ru_load(w, n, b, s64);
+    R32 s = ru_to32(s64);   // the rules run on the 32 dark squares; the stored layout stays the reference-facing one
     const uint64_t key = seed + (first_id + (uint64_t)b) * ELF_GOLDEN + step_base;
     for (int step = 0; step < nply; ++step) {
       uint64_t m[5];
@@ -115,7 +116,7 @@ ru_playout_kernel(uint64_t* __restrict__ w, int n, int nply, uint64_t seed, uint
       RPROF_ADD(7);
       ++moves;
     }
-    ru_store(w, n, b, s);
+    ru_store(w, n, b, ru_to64(s));
   }
 #ifdef RU_PROF
   for (int k = 0; k < 16; ++k) {

@@ -57,8 +57,70 @@ __host__ __device__ constexpr int ru_base(int k, int d) {
 }
 static_assert(ru_base(3, 7) + ru_popc(ru_valid(3, 7)) == RU_ACTIONS, "russian action table size");
 
-// action -> from | to << 6, generated by the same rule (descending from-square inside a group)
-struct RuActTab { uint16_t ft[RU_ACTIONS]; };
+// ---- the 32 dark squares: index i = y*4 + (x >> 1) = (square y*8 + x) >> 1 ------------------------------------
+// All rule code below works on 32-bit sets of dark squares (half the instructions of the 64-bit board for every
+// and / or / popcount / lowest-bit step).  Rows alternate: in even rows the dark squares are x = 1,3,5,7, in odd rows
+// x = 0,2,4,6, so one diagonal step is i +- 4 for one row parity and i +- 3 / +- 5 for the other; two and four steps
+// along a diagonal are the same shift for every row.
+__host__ __device__ constexpr uint32_t ru_c32(uint64_t b) {   // compress (constant expressions / host)
+  uint32_t r = 0;
+  for (int i = 0; i < 32; ++i) { const int y = i >> 2, x = 2 * (i & 3) + ((y & 1) ? 0 : 1); r |= (uint32_t)((b >> (y * 8 + x)) & 1) << i; }
+  return r;
+}
+__host__ __device__ constexpr uint64_t ru_e64(uint32_t c) {   // expand
+  uint64_t r = 0;
+  for (int i = 0; i < 32; ++i) { const int y = i >> 2, x = 2 * (i & 3) + ((y & 1) ? 0 : 1); r |= (uint64_t)((c >> i) & 1) << (y * 8 + x); }
+  return r;
+}
+// the same on the device: bit tricks instead of 32 steps (a board is converted when it is loaded and stored only)
+__device__ inline uint32_t ru_c16(uint32_t h) {   // four rows (one 32-bit half) -> 16 bits
+  uint32_t t = ((h >> 1) & 0x00550055u) | (h & 0x55005500u);   // every row's dark squares at bits 0,2,4,6 of its byte
+  t = (t | (t >> 1)) & 0x33333333u;
+  t = (t | (t >> 2)) & 0x0F0F0F0Fu;
+  t = (t | (t >> 4)) & 0x00FF00FFu;
+  return (t | (t >> 8)) & 0xFFFFu;
+}
+__device__ inline uint32_t ru_compress(uint64_t b) { return ru_c16((uint32_t)b) | (ru_c16((uint32_t)(b >> 32)) << 16); }
+__device__ inline uint32_t ru_e32(uint32_t c) {   // 16 bits -> four rows
+  uint32_t t = (c | (c << 8)) & 0x00FF00FFu;
+  t = (t | (t << 4)) & 0x0F0F0F0Fu;
+  t = (t | (t << 2)) & 0x33333333u;
+  t = (t | (t << 1)) & 0x55555555u;
+  return ((t & 0x00550055u) << 1) | (t & 0x55005500u);
+}
+__device__ inline uint64_t ru_expand(uint32_t c) { return (uint64_t)ru_e32(c & 0xFFFFu) | ((uint64_t)ru_e32(c >> 16) << 32); }
+
+// one, two and four steps along k (bits that would leave the board are dropped)
+__host__ __device__ constexpr uint32_t r_sh1(uint32_t b, int k) {
+  return k == 0 ? ((b & 0x07070707u) >> 3) | ((b & 0xF0F0F0F0u) >> 4)
+       : k == 1 ? ((b & 0x0F0F0F0Fu) >> 4) | ((b & 0xE0E0E0E0u) >> 5)
+       : k == 2 ? ((b & 0x0F0F0F0Fu) << 4) | ((b & 0xE0E0E0E0u) << 3)
+                : ((b & 0x07070707u) << 5) | ((b & 0xF0F0F0F0u) << 4);
+}
+__host__ __device__ constexpr uint32_t r_sh2(uint32_t b, int k) {
+  return k == 0 ? (b & 0x77777777u) >> 7 : k == 1 ? (b & 0xEEEEEEEEu) >> 9 : k == 2 ? (b & 0xEEEEEEEEu) << 7 : (b & 0x77777777u) << 9;
+}
+__host__ __device__ constexpr uint32_t r_sh4(uint32_t b, int k) {
+  return k == 0 ? (b & 0x33333333u) >> 14 : k == 1 ? (b & 0xCCCCCCCCu) >> 18 : k == 2 ? (b & 0xCCCCCCCCu) << 14 : (b & 0x33333333u) << 18;
+}
+// the shifts agree with the 64-bit board for every square and direction
+constexpr bool ru_check_shifts() {
+  for (int k = 0; k < 4; ++k)
+    for (int i = 0; i < 32; ++i) {
+      const uint32_t b = 1u << i;
+      if (r_sh1(b, k) != ru_c32(ru_sh(ru_e64(b), k))) return false;
+      if (r_sh2(b, k) != r_sh1(r_sh1(b, k), k)) return false;
+      if (r_sh4(b, k) != r_sh2(r_sh2(b, k), k)) return false;
+    }
+  return true;
+}
+static_assert(ru_check_shifts(), "russian 32-bit diagonal shifts");
+static_assert(ru_c32(RU_DARK) == 0xFFFFFFFFu && ru_e64(0xFFFFFFFFu) == RU_DARK, "russian dark-square packing");
+__host__ __device__ constexpr uint32_t r_valid(int k, int d) { return ru_c32(ru_valid(k, d)); }
+
+// action -> from | to << 6 (64-bit squares) and the dark squares strictly between the two; generated by the same rule
+// as the reference's table (descending from-square inside a group)
+struct RuActTab { uint2 e[RU_ACTIONS]; };
 constexpr RuActTab ru_make_acttab() {
   RuActTab t{};
   int n = 0;
@@ -67,22 +129,35 @@ constexpr RuActTab ru_make_acttab() {
       uint64_t v = ru_valid(k, d);
       for (int s = 63; s >= 0; --s)
         if ((v >> s) & 1) {
-          int to = (k < 2) ? s - (k == 0 ? 7 : 9) * d : s + (k == 2 ? 7 : 9) * d;
-          t.ft[n++] = (uint16_t)(s | (to << 6));
+          const int step = (k < 2) ? -(k == 0 ? 7 : 9) : (k == 2 ? 7 : 9);
+          uint64_t between = 0;
+          for (int i = 1; i < d; ++i) between |= 1ull << (s + step * i);
+          t.e[n].x = (uint32_t)(s | ((s + step * d) << 6));
+          t.e[n].y = ru_c32(between);
+          ++n;
         }
     }
   return t;
 }
 static __constant__ RuActTab c_ru_act = ru_make_acttab();
 
-// Kogge-Stone occluded fill: everything reachable from `gen` along k through `pro` (gen included)
-__device__ inline uint64_t ru_fill(uint64_t gen, uint64_t pro, int k) {
-  pro &= ru_wrap(k);
-  gen |= pro & ru_shn(gen, k, 1);
-  pro &= ru_shn(pro, k, 1);
-  gen |= pro & ru_shn(gen, k, 2);
-  pro &= ru_shn(pro, k, 2);
-  gen |= pro & ru_shn(gen, k, 4);
+struct R32 { uint32_t wp, wk, bp, bk; uint64_t w4; };
+__device__ inline R32 ru_to32(const Ru& s) { return R32{ru_compress(s.wp), ru_compress(s.wk), ru_compress(s.bp), ru_compress(s.bk), s.w4}; }
+__device__ inline Ru ru_to64(const R32& s) { return Ru{ru_expand(s.wp), ru_expand(s.wk), ru_expand(s.bp), ru_expand(s.bk), s.w4}; }
+
+// Kogge-Stone occluded fill along k: everything reachable from `gen` through empty squares (gen included).  The
+// propagators (empty squares whose predecessor(s) along k are empty too) depend on the position only: made once.
+struct RPro { uint32_t e, p2[4], p4[4]; };
+__device__ inline RPro r_pro(uint32_t empty) {
+  RPro P; P.e = empty;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { P.p2[k] = empty & r_sh1(empty, k); P.p4[k] = P.p2[k] & r_sh2(P.p2[k], k); }
+  return P;
+}
+__device__ inline uint32_t r_fill(uint32_t gen, const RPro& P, int k) {
+  gen |= P.e & r_sh1(gen, k);
+  gen |= P.p2[k] & r_sh2(gen, k);
+  gen |= P.p4[k] & r_sh4(gen, k);
   return gen;
 }
 
@@ -95,26 +170,25 @@ __device__ inline void ru_place_group(uint64_t m[5], uint32_t g, int k, int d) {
   m[w0] |= (uint64_t)g << sh;
   if (sh + size > 64) m[w0 + 1] |= (uint64_t)g >> (64 - sh);
 }
-
 // all from-squares of `from` move d steps along k
-__device__ inline void ru_emit_group(uint64_t m[5], uint64_t from, int k, int d) {
-  const uint64_t valid = ru_valid(k, d);
+__device__ inline void ru_emit_group(uint64_t m[5], uint32_t from, int k, int d) {
+  const uint32_t valid = r_valid(k, d);
   uint32_t g = 0;
   while (from) {
-    uint64_t o = from & (0 - from);
+    const uint32_t o = from & (0u - from);
     from ^= o;
-    g |= 1u << __popcll(valid & ~(o | (o - 1)));
+    g |= 1u << __popc(valid & ~(o | (o - 1u)));
   }
   ru_place_group(m, g, k, d);
 }
 // one origin, a set of destinations along k
-__device__ inline void ru_emit_ray(uint64_t m[5], uint64_t o, uint64_t dests, int k) {
-  const uint64_t above = ~(o | (o - 1));
-  uint64_t t = o;
+__device__ inline void ru_emit_ray(uint64_t m[5], uint32_t o, uint32_t dests, int k) {
+  const uint32_t above = ~(o | (o - 1u));
+  uint32_t t = o;
 #pragma unroll
   for (int d = 1; d < 8; ++d) {
-    t = ru_sh(t, k);
-    ru_place_group(m, (dests & t) ? 1u << __popcll(ru_valid(k, d) & above) : 0u, k, d);
+    t = r_sh1(t, k);
+    ru_place_group(m, (dests & t) ? 1u << __popc(r_valid(k, d) & above) : 0u, k, d);
   }
 }
 
@@ -122,18 +196,23 @@ __device__ inline void ru_clear(Ru& s) {  // ClearBoard CheckersBoard.cc:10-33
   s.wp = RU_DARK & 0xFFFFFFull; s.wk = 0; s.bp = RU_DARK & (0xFFFFFFull << 40); s.bk = 0;
   s.w4 = (1ull << 8) | ((uint64_t)RU_M_INVALID << 24);
 }
+__device__ inline void ru_clear(R32& s) {
+  s.wp = 0x00000FFFu; s.wk = 0; s.bp = 0xFFF00000u; s.bk = 0;
+  s.w4 = (1ull << 8) | ((uint64_t)RU_M_INVALID << 24);
+}
+static_assert(ru_c32(RU_DARK & 0xFFFFFFull) == 0x00000FFFu && ru_c32(RU_DARK & (0xFFFFFFull << 40)) == 0xFFF00000u, "russian start position");
 
 // getAllMoves CheckersBoard.cc:259-273 -> 280-bit legal mask
-__device__ inline void ru_moves(const Ru& s, uint64_t m[5]) {
+__device__ inline void ru_moves(const R32& s, uint64_t m[5]) {
 #pragma unroll
   for (int i = 0; i < 5; ++i) m[i] = 0;
   const bool white = ru_white(s.w4);
-  uint64_t P = white ? s.wp : s.bp, K = white ? s.wk : s.bk;
-  const uint64_t enemy = white ? (s.bp | s.bk) : (s.wp | s.wk);
-  const uint64_t occ = s.wp | s.wk | s.bp | s.bk, empty = ~occ;
+  uint32_t P = white ? s.wp : s.bp, K = white ? s.wk : s.bk;
+  const uint32_t enemy = white ? (s.bp | s.bk) : (s.wp | s.wk);
+  const uint32_t empty = ~(s.wp | s.wk | s.bp | s.bk);
   const bool has_next = (s.w4 >> 1) & 1;
   if (has_next) {  // only the piece that just captured may move, and only by capturing (:262-263)
-    uint64_t nb = 1ull << ((((s.w4 >> 2) & 7) << 3) | ((s.w4 >> 5) & 7));  // next_y<<2 | next_x<<5
+    const uint32_t nb = 1u << (((((uint32_t)(s.w4 >> 2) & 7u) << 3) | ((uint32_t)(s.w4 >> 5) & 7u)) >> 1);  // next_y<<2 | next_x<<5
     K = nb & (s.wk | s.bk);
     P = nb & ~(s.wk | s.bk);
   }
@@ -142,8 +221,8 @@ __device__ inline void ru_moves(const Ru& s, uint64_t m[5]) {
   // _pawnJumpInDirection :593-628 - all pawns at once
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    uint64_t land = ru_sh(ru_sh(P, k) & enemy, k) & empty;
-    uint64_t from = ru_sh(ru_sh(land, k ^ 2), k ^ 2);
+    const uint32_t land = r_sh1(r_sh1(P, k) & enemy, k) & empty;
+    const uint32_t from = r_sh1(r_sh1(land, k ^ 2), k ^ 2);
     any |= from != 0;
     ru_emit_group(m, from, k, 2);
   }
@@ -152,40 +231,43 @@ __device__ inline void ru_moves(const Ru& s, uint64_t m[5]) {
   // included, so the occluded fill from the whole king set is the union of the kings' rays: "the first piece on some
   // king's ray along k is an enemy with an empty square behind it" is one fill per direction for all kings, and every
   // such piece belongs to exactly one king (found by walking back from it).
-  uint64_t capl[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint64_t cap = ru_sh(ru_fill(K, empty, k), k) & enemy;
-    capl[k] = cap & ru_sh(ru_sh(cap, k) & empty, k ^ 2);
-  }
-  RPROF_ADD(1);
-  if (__any((capl[0] | capl[1] | capl[2] | capl[3]) != 0)) {
-    // F0[d] = squares from which a king sees, along d, empty squares, an enemy, an empty square (_kingJumpCheck
-    // :412-453) on the board as it stands.  The reference tests the landing squares with the captured piece lifted
-    // and the king still on its origin (:488): for a landing square behind the captured piece that changes nothing
-    // along k and along the two crossing diagonals (neither contains the lifted square), and looking back along
-    // k ^ 2 the first piece behind the lifted one is the capturing king itself - never a capture.  So the test is
-    // the three other directions on the unchanged board, shared by every capture of the position.
-    uint64_t F0[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const uint64_t T = enemy & ru_sh(empty, d ^ 2);
-      F0[d] = ru_fill(ru_sh(T, d ^ 2) & empty, empty, d ^ 2);
-    }
+  if (__any(K != 0)) {
+    const RPro E = r_pro(empty);
+    uint32_t capl[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const uint64_t C = F0[k] | F0[k ^ 1] | F0[k ^ 3];
-      for (uint64_t cc = capl[k]; cc;) {
-        const uint64_t c = cc & (0 - cc);
-        cc ^= c;
-        RPROF_INC(9);
-        uint64_t L = ru_fill(ru_sh(c, k), empty, k);             // landing squares behind the captured piece
-        const uint64_t Lc = L & C;
-        if (Lc) L = (k >= 2) ? (Lc & (0 - Lc)) : (1ull << (63 - __clzll((long long)Lc)));  // nearest one only (:505-513)
-        const uint64_t t = ru_sh(c, k ^ 2);                      // the square in front of it: the king, or empty
-        const uint64_t o = K & (t | ru_sh(ru_fill(t & empty, empty, k ^ 2), k ^ 2));
-        ru_emit_ray(m, o, L, k);
-        any = true;
+      const uint32_t cap = r_sh1(r_fill(K, E, k), k) & enemy;
+      capl[k] = cap & r_sh1(r_sh1(cap, k) & empty, k ^ 2);
+    }
+    RPROF_ADD(1);
+    if (__any((capl[0] | capl[1] | capl[2] | capl[3]) != 0)) {
+      // F0[d] = squares from which a king sees, along d, empty squares, an enemy, an empty square (_kingJumpCheck
+      // :412-453) on the board as it stands.  The reference tests the landing squares with the captured piece lifted
+      // and the king still on its origin (:488): for a landing square behind the captured piece that changes nothing
+      // along k and along the two crossing diagonals (neither contains the lifted square), and looking back along
+      // k ^ 2 the first piece behind the lifted one is the capturing king itself - never a capture.  So the test is
+      // the three other directions on the unchanged board, shared by every capture of the position.
+      uint32_t F0[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const uint32_t T = enemy & r_sh1(empty, d ^ 2);
+        F0[d] = r_fill(r_sh1(T, d ^ 2) & empty, E, d ^ 2);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t C = F0[k] | F0[k ^ 1] | F0[k ^ 3];
+        for (uint32_t cc = capl[k]; cc;) {
+          const uint32_t c = cc & (0u - cc);
+          cc ^= c;
+          RPROF_INC(9);
+          uint32_t L = r_fill(r_sh1(c, k), E, k);                // landing squares behind the captured piece
+          const uint32_t Lc = L & C;
+          if (Lc) L = (k >= 2) ? (Lc & (0u - Lc)) : (0x80000000u >> __clz((int)Lc));  // nearest one only (:505-513)
+          const uint32_t t = r_sh1(c, k ^ 2);                    // the square in front of it: the king, or empty
+          const uint32_t o = K & (t | r_sh1(r_fill(t & empty, E, k ^ 2), k ^ 2));
+          ru_emit_ray(m, o, L, k);
+          any = true;
+        }
       }
     }
   }
@@ -196,13 +278,13 @@ __device__ inline void ru_moves(const Ru& s, uint64_t m[5]) {
   // forward directions are walked once with per-lane direction masks instead of all four directions in turn.
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const uint64_t from = P & (white ? ru_sh(empty, j) : ru_sh(empty, 2 + j));   // next square along k = (2 + j | j) empty
-    const uint64_t valid = white ? ru_valid(2 + j, 1) : ru_valid(j, 1);
+    const uint32_t from = P & (white ? r_sh1(empty, j) : r_sh1(empty, 2 + j));   // next square along k = (2 + j | j) empty
+    const uint32_t valid = white ? r_valid(2 + j, 1) : r_valid(j, 1);
     uint32_t g = 0;
-    for (uint64_t f = from; f;) {
-      const uint64_t o = f & (0 - f);
+    for (uint32_t f = from; f;) {
+      const uint32_t o = f & (0u - f);
       f ^= o;
-      g |= 1u << __popcll(valid & ~(o | (o - 1)));
+      g |= 1u << __popc(valid & ~(o | (o - 1u)));
     }
     ru_place_group(m, white ? g : 0u, 2 + j, 1);
     ru_place_group(m, white ? 0u : g, j, 1);
@@ -215,11 +297,11 @@ __device__ inline void ru_moves(const Ru& s, uint64_t m[5]) {
   if (__any(K != 0)) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      uint64_t R = ~0ull;
+      uint32_t R = 0xFFFFFFFFu;
 #pragma unroll
       for (int d = 1; d < 8; ++d) {
-        R = ru_sh(empty & R, k ^ 2);
-        const uint64_t from = K & R;
+        R = r_sh1(empty & R, k ^ 2);
+        const uint32_t from = K & R;
         if (!__any(from != 0)) break;
         RPROF_INC(10);
         ru_emit_group(m, from, k, d);
@@ -228,38 +310,37 @@ __device__ inline void ru_moves(const Ru& s, uint64_t m[5]) {
   }
   RPROF_ADD(4);
 }
+__device__ inline void ru_moves(const Ru& s, uint64_t m[5]) { ru_moves(ru_to32(s), m); }
 
 __device__ inline int ru_count(const uint64_t m[5]) {
   return __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]) + __popcll(m[4]);
 }
 
 // CheckersPlay :36-82 (action must be legal)
-// ft_tab: the action table (from | to << 6); a kernel that plays many moves keeps a copy in LDS
-template <class FT>
-__device__ inline void ru_play(Ru& s, int action, FT ft_tab) {
-  const uint32_t ft = ft_tab[action];
-  const int fs = ft & 63, ts = ft >> 6;
-  const uint64_t fb = 1ull << fs, tb = 1ull << ts;
-  // the squares of the diagonal between the two (origin excluded): every 9th or every 7th bit from the lower one up
-  const int lo = min(fs, ts), hi = max(fs, ts);
-  const bool diag9 = ((ts & 7) > (fs & 7)) == (ts > fs);
-  const uint64_t line = diag9 ? 0x8040201008040201ull : 0x8102040810204081ull;
-  const uint64_t path = (line << lo) & ((2ull << hi) - 1) & ~fb;
+// tab: the action table (c_ru_act.e); a kernel that plays many moves keeps a copy in LDS
+template <class TAB>
+__device__ inline void ru_play(R32& s, int action, TAB tab) {
+  const uint2 e = tab[action];
+  const int fs = e.x & 63, ts = e.x >> 6;
+  const uint32_t fb = 1u << (fs >> 1), tb = 1u << (ts >> 1);
   const bool is_king = (fb & (s.wk | s.bk)) != 0;
   const bool white_piece = (fb & (s.wp | s.wk)) != 0;
-  const uint64_t cap = path & (s.wp | s.wk | s.bp | s.bk);
+  const uint32_t cap = e.y & (s.wp | s.wk | s.bp | s.bk);   // the piece between origin and destination, if any
   uint64_t w4 = s.w4;
   if (cap) {
     s.wp &= ~cap; s.wk &= ~cap; s.bp &= ~cap; s.bk &= ~cap;
     // continuation is evaluated from the destination while the piece still stands on its origin (:58-66)
     const bool white = ru_white(w4);
-    const uint64_t enemy = white ? (s.bp | s.bk) : (s.wp | s.wk);
-    const uint64_t empty = ~(s.wp | s.wk | s.bp | s.bk);
+    const uint32_t enemy = white ? (s.bp | s.bk) : (s.wp | s.wk);
+    const uint32_t empty = ~(s.wp | s.wk | s.bp | s.bk);
     bool more = false;
+    if (is_king) {
+      const RPro E = r_pro(empty);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      uint64_t first = is_king ? ru_sh(ru_fill(tb, empty, k), k) : ru_sh(tb, k);
-      more |= (ru_sh(first & enemy, k) & empty) != 0;
+      for (int k = 0; k < 4; ++k) more |= (r_sh1(r_sh1(r_fill(tb, E, k), k) & enemy, k) & empty) != 0;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) more |= (r_sh1(r_sh1(tb, k) & enemy, k) & empty) != 0;
     }
     w4 &= ~0xFEull;
     if (more) w4 |= 2ull | ((uint64_t)(ts >> 3) << 2) | ((uint64_t)(ts & 7) << 5);
@@ -275,8 +356,7 @@ __device__ inline void ru_play(Ru& s, int action, FT ft_tab) {
   w4 = (w4 & 0xFFull) | (ply << 8) | ((uint64_t)action << 24);
   s.w4 = w4;
 }
-
-__device__ inline void ru_play(Ru& s, int action) { ru_play(s, action, c_ru_act.ft); }
+__device__ inline void ru_play(Ru& s, int action) { R32 r = ru_to32(s); ru_play(r, action, c_ru_act.e); s = ru_to64(r); }
 
 __device__ inline void ru_load(const uint64_t* __restrict__ w, int n, int b, Ru& s) {
   s.wp = w[0 * (size_t)n + b]; s.wk = w[1 * (size_t)n + b]; s.bp = w[2 * (size_t)n + b];
