@@ -134,15 +134,15 @@ __device__ inline uint32_t kth_bit(uint32_t x, int k) {
 }
 
 // Random-legal playouts: nply steps per launch with the board in registers.
-#ifndef GO_PLAYOUT_BLOCK
-#define GO_PLAYOUT_BLOCK 64   // occupancy experiments only (benchmarks/_build_prof_lib.sh GO_PLAYOUT_BLOCK=256)
-#endif
-#ifdef GO_PLAYOUT_WAVES
-__attribute__((amdgpu_waves_per_eu(GO_PLAYOUT_WAVES, GO_PLAYOUT_WAVES)))
-#endif
-__global__ void __launch_bounds__(GO_PLAYOUT_BLOCK)
-go_playout_kernel(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t seed, uint64_t first_id,
-                  uint64_t step_base, unsigned long long* __restrict__ moves_out) {
+// Two kernels share the body.  The plain one (64-thread blocks, no register limit: 294 registers, nothing spilled)
+// is the one for up to one wave per SIMD - BASELINE.json configs[1]'s 65,536 boards on the MI355X's 1,024 SIMDs.
+// A lone wave issues an integer instruction only every ~5 cycles, a SIMD takes one every ~2.7 (benchmarks/ubench/):
+// for larger slabs the dense kernel (256-thread blocks sharing the LDS tables, at most 256 registers so that two
+// waves fit a SIMD, a few registers spilled) runs the same boards 30-38 % faster than queueing them behind the
+// first 65,536.
+__device__ __forceinline__ void
+go_playout_body(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t seed, uint64_t first_id,
+                uint64_t step_base, unsigned long long* __restrict__ moves_out) {
   __shared__ uint64_t z[GO_ZWORDS];
   __shared__ uint32_t s_mod[2][GO_POINTS + 1];   // per legal-move count n: floor((2^32 - 1) / n), 2^32 mod n
   for (int n = threadIdx.x + 1; n <= GO_POINTS; n += blockDim.x) {
@@ -205,6 +205,17 @@ go_playout_kernel(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t s
     for (int o = 32; o > 0; o >>= 1) moves += __shfl_down(moves, o);
     if ((threadIdx.x & 63) == 0) atomicAdd(moves_out, moves);
   }
+}
+
+__global__ void __launch_bounds__(64)
+go_playout_kernel(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t seed, uint64_t first_id,
+                  uint64_t step_base, unsigned long long* __restrict__ moves_out) {
+  go_playout_body(d, gz, nply, seed, first_id, step_base, moves_out);
+}
+__attribute__((amdgpu_waves_per_eu(2, 2))) __global__ void __launch_bounds__(256)
+go_playout_dense_kernel(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t seed, uint64_t first_id,
+                        uint64_t step_base, unsigned long long* __restrict__ moves_out) {
+  go_playout_body(d, gz, nply, seed, first_id, step_base, moves_out);
 }
 
 // Tromp-Taylor area score, komi 7.5 (oracle/go.c go_tt_score); value = 0 unless terminated
@@ -289,8 +300,11 @@ struct GoSlab : BoardSlab {
     (void)hipFree(d.table); (void)hipFree(gz); (void)hipFree(aos); (void)hipFree(d.hist); (void)hipFree(d.hmeta);
   }
   int grid() const { return (n + 63) / 64; }
+  int one_wave_per_simd = 65536;   // lanes of one wave on every SIMD of the device (set in alloc)
   int alloc() override {
     d.n = n;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) one_wave_per_simd = cus * 4 * 64;
     size_t N = (size_t)n;
     if (hipMalloc(&d.rows, sizeof(uint32_t) * NROWW * N) != hipSuccess ||
         hipMalloc(&d.meta, sizeof(uint32_t) * 4 * N) != hipSuccess ||
@@ -365,8 +379,12 @@ struct GoSlab : BoardSlab {
     return ELFHIP_OK;
   }
   int playout(int nply, uint64_t seed, uint64_t first_id, unsigned long long* d_moves) override {
-    hipLaunchKernelGGL(go_playout_kernel, dim3((n + GO_PLAYOUT_BLOCK - 1) / GO_PLAYOUT_BLOCK), dim3(GO_PLAYOUT_BLOCK), 0, stream, d, gz, nply, seed, first_id,
-                       step_counter, d_moves);
+    if (n > one_wave_per_simd)   // more boards than one wave per SIMD can hold: two waves per SIMD, see go_playout_body
+      hipLaunchKernelGGL(go_playout_dense_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d, gz, nply, seed, first_id,
+                         step_counter, d_moves);
+    else
+      hipLaunchKernelGGL(go_playout_kernel, dim3(grid()), dim3(64), 0, stream, d, gz, nply, seed, first_id,
+                         step_counter, d_moves);
     HIPCHECK(hipGetLastError());
     step_counter += (uint64_t)nply;
     return ELFHIP_OK;

@@ -110,6 +110,31 @@ def test_playout_kernel_vs_oracle(torch_cuda):
     assert ply.max() < 722 and moves < n * 900
 
 
+def test_dense_playout_kernel_matches_plain(torch_cuda):
+    """A slab with more boards than one wave per SIMD holds (65,536 on the MI355X) runs the playout kernel built
+    for two waves per SIMD (256-thread blocks, register limit); same body, so its boards must come out exactly
+    as the plain kernel's - which the test above holds against the oracle - on the same board ids."""
+    torch = torch_cuda
+    from elf_amd.boards import BoardBatch, GO19
+    n0, n1 = 65536, 2048
+    big = BoardBatch(GO19, n0 + n1)
+    cb = torch.zeros(1, dtype=torch.int64, device="cuda")
+    big.playout(150, seed=0x5EED0003, first_board_id=5, counter=cb)
+    big.playout(100, seed=0x5EED0003, first_board_id=5, counter=cb)
+    got = big.export_states()
+    del big
+    parts, moves = [], 0
+    for first, n in ((5, n0), (5 + n0, n1)):
+        bb = BoardBatch(GO19, n)
+        c = torch.zeros(1, dtype=torch.int64, device="cuda")
+        bb.playout(150, seed=0x5EED0003, first_board_id=first, counter=c)
+        bb.playout(100, seed=0x5EED0003, first_board_id=first, counter=c)
+        parts.append(bb.export_states()); moves += int(c.item())
+        del bb
+    assert np.array_equal(got, np.concatenate(parts))
+    assert int(cb.item()) == moves
+
+
 def test_full_size_properties(torch_cuda):
     """65,536 boards (BASELINE configs[1] size): oracle-free invariants after 200 plies:
     colours disjoint, hash == from-scratch Zobrist, no stone group without liberties, legal mask
