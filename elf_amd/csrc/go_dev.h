@@ -290,17 +290,14 @@ __device__ inline void go_place(GoS& s, bool act, uint32_t r, uint32_t bit, cons
   PROF_ADD(3);
   // ---- the (up to four) opponent groups that lost this liberty.  None of them carries an AT bit:
   //      a neighbour in atari was just captured. ----
+#ifdef GO_FIXED_DIRECTIONS   // A/B only: one job per direction, whatever the lanes hold there
   const bool crowded = !__any(act && s.ply < 48);
 #pragma unroll 1
   for (int d = 0; d < 4; ++d) {  // 0 up, 1 down, 2 left, 3 right
-    // the neighbouring point in direction d: the stone's row set moved up / down a row or left / right a column
-    // (d is a scalar loop counter: four small copies of the seed loop behind scalar branches, one shared growth)
     if (d == 0) { ROWS(i) F[i] = (i + 1 < GN ? ST[i + 1 < GN ? i + 1 : 0] : 0u) & s.Q[i]; }
     else if (d == 1) { ROWS(i) F[i] = (i > 0 ? ST[i > 0 ? i - 1 : 0] : 0u) & s.Q[i]; }
     else if (d == 2) { ROWS(i) F[i] = (ST[i] >> 1) & s.Q[i]; }
     else { ROWS(i) F[i] = (ST[i] << 1) & s.Q[i]; }   // Q has no bits above column 18
-    // once the board has filled up some lane of the wave always has an opponent stone in this direction: the test
-    // (19 ORs and a ballot) is only made while every lane is early in its game
     const bool any = crowded || go_any_rows(F);
     PROF_ADD(0);
     if (!any) continue;
@@ -309,6 +306,34 @@ __device__ inline void go_place(GoS& s, bool act, uint32_t r, uint32_t bit, cons
     go_group_status(s, F, s.Q, E, false, sz, lb);
     PROF_ADD(3);
   }
+#else
+  // Every lane walks ITS OWN neighbours (up, down, left, right, the ones that hold an opponent stone, in that
+  // order): the wave runs as many jobs as its busiest lane has opponent neighbours - one or two early in a game,
+  // three late (a point with four is hardly ever legal) - instead of one per direction.  A direction without a
+  // stone was a job that changed nothing, so the boards come out the same.
+  uint32_t q_up = 0, q_dn = 0, q_0 = 0;
+  ROWS(i) {
+    q_up |= (i + 1 < GN ? ST[i + 1 < GN ? i + 1 : 0] : 0u) & s.Q[i];   // row r - 1, the stone's column
+    q_dn |= (i > 0 ? ST[i > 0 ? i - 1 : 0] : 0u) & s.Q[i];             // row r + 1
+    q_0 = (uint32_t)i == r ? s.Q[i] : q_0;
+  }
+  const bool e0 = q_up != 0, e1 = q_dn != 0, e2 = (q_0 & (bit >> 1)) != 0, e3 = (q_0 & (bit << 1)) != 0;
+  const int c1 = e0 ? 1 : 0, c2 = c1 + (e1 ? 1 : 0), c3 = c2 + (e2 ? 1 : 0), cnt = c3 + (e3 ? 1 : 0);
+  PROF_ADD(0);
+#pragma unroll 1
+  for (int j = 0; j < 4; ++j) {
+    if (!__any(cnt > j)) break;
+    const bool t0 = e0 && j == 0, t1 = e1 && c1 == j, t2 = e2 && c2 == j, t3 = e3 && c3 == j;
+    const uint32_t rs = t0 ? r - 1u : (t1 ? r + 1u : r);
+    const uint32_t bs = (t0 || t1) ? bit : (t2 ? bit >> 1 : (t3 ? bit << 1 : 0u));
+    ROWS(i) F[i] = (uint32_t)i == rs ? bs : 0u;
+    PROF_ADD(0);
+    PROF_INC(13 + j, 1);
+    int sz, lb;
+    go_group_status(s, F, s.Q, E, false, sz, lb);
+    PROF_ADD(3);
+  }
+#endif
   if (act) {
     s.capP += ncap;
     s.ko = (ncap == 1 && own_size == 1 && own_libs == 1) ? cap_pt : NO_POINT;
