@@ -173,7 +173,8 @@ go_playout_body(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t see
     }
     const bool act = valid && !term;
     uint32_t L[GN];
-    int n = go_legal_rows(s, L);
+    int inc[GN];   // legal points up to and including each row
+    int n = go_legal_rows(s, L, inc);
     uint32_t a = GO_PASS;
     if (act && n > 0) {
       const uint64_t r = elf_splitmix64(key + (uint64_t)step);
@@ -181,6 +182,7 @@ go_playout_body(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t see
       const uint32_t rc = s_mod[0][n], p32 = s_mod[1][n];
       const uint32_t hi = mod_small((uint32_t)(r >> 32), (uint32_t)n, rc), lo = mod_small((uint32_t)r, (uint32_t)n, rc);
       int k = (int)mod_small(hi * p32 + lo, (uint32_t)n, rc);
+#ifdef GO_SELECT_SCAN   // A/B only: the row by a running scan
       uint32_t row = 0, rowbits = 0;
       bool found = false;
       ROWS(i) {
@@ -189,6 +191,17 @@ go_playout_body(GoDev d, const uint64_t* __restrict__ gz, int nply, uint64_t see
         if (here) { row = i; rowbits = L[i]; found = true; }
         if (!found) k -= c;
       }
+#else
+      // the row that holds the k-th legal point = the number of rows whose running count is still <= k
+      // (a compare and an add-with-carry per row), then that row's mask and the count before it by row index
+      uint32_t row = 0;
+#pragma unroll
+      for (int i = 0; i < GN - 1; ++i) row += inc[i] <= k ? 1u : 0u;
+      uint32_t rowbits = L[0]; int before = 0;
+#pragma unroll
+      for (int i = 1; i < GN; ++i) { const bool here = row == (uint32_t)i; rowbits = here ? L[i] : rowbits; before = here ? inc[i - 1] : before; }
+      k -= before;
+#endif
       a = row * 19 + kth_bit(rowbits, k);
     }
     PROF_ADD(4);

@@ -124,6 +124,25 @@ __device__ inline int go_legal_rows(const GoS& s, uint32_t (&L)[GN]) {
   return n;
 }
 
+// the same, also giving the running count of legal points after every row (for picking the k-th one)
+__device__ inline int go_legal_rows(const GoS& s, uint32_t (&L)[GN], int (&inc)[GN]) {
+  uint32_t T[GN], E[GN];
+  ROWS(i) {
+    E[i] = ~(s.P[i] | s.Q[i]) & FULL;
+    T[i] = E[i] | (s.P[i] & ~s.AT[i]) | (s.Q[i] & s.AT[i]);
+  }
+  const uint32_t kr = s.ko == NO_POINT ? 99u : s.ko / 19u, kb = s.ko == NO_POINT ? 0u : 1u << (s.ko % 19u);
+  int n = 0;
+  ROWS(i) {
+    uint32_t l = E[i] & NBR(T, i);
+    l &= ~((uint32_t)i == kr ? kb : 0u);
+    L[i] = l;
+    n += __popc(l);
+    inc[i] = n;
+  }
+  return n;
+}
+
 // One growth pass over the whole board, in place: rows in ascending (DOWN) or descending order.  A row takes the
 // final value of its predecessor in sweep order and is then flooded EXACTLY along the row: for a seed set x inside a
 // row mask m, (m + x) carries through every run of m upwards from its lowest seed, so ((m + x) ^ m) & m are the run
