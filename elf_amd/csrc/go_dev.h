@@ -153,6 +153,13 @@ __device__ inline int go_legal_rows(const GoS& s, uint32_t (&L)[GN], int (&inc)[
 //   nlib = distinct empty points (E) adjacent to F as the pass leaves it (each row is counted one step later,
 //          when both of its vertical neighbours are final): a lower bound of the group's liberties, exact when pend == 0.
 // ~16 VALU instructions per row.
+// acc += popcount(x) as ONE instruction (v_bcnt_u32_b32 adds its third operand); left to itself the compiler counts
+// two rows separately and joins them with a three-way add - three instructions for two rows
+#ifdef GO_POPC_PLAIN   // A/B only
+#define GO_POPC_ACC(acc, x) (acc) += __popc(x)
+#else
+#define GO_POPC_ACC(acc, x) do { const uint32_t _x = (x); asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(_x)); } while (0)
+#endif
 template <bool EVAL, bool DOWN>
 __device__ inline void go_grow(uint32_t (&F)[GN], const uint32_t (&M)[GN], const uint32_t (&E)[GN], uint32_t& pend, int& nlib) {
   pend = 0; nlib = 0;
@@ -170,11 +177,11 @@ __device__ inline void go_grow(uint32_t (&F)[GN], const uint32_t (&M)[GN], const
     F[i] = g;
     if (k > 0) {
       pend |= g & M[ip] & ~prev;
-      if (EVAL) nlib += __popc(((prev << 1) | (prev >> 1) | prev2 | g) & E[ip]);
+      if (EVAL) GO_POPC_ACC(nlib, ((prev << 1) | (prev >> 1) | prev2 | g) & E[ip]);
     }
     prev2 = prev; prev = g;
   }
-  if (EVAL) nlib += __popc(((prev << 1) | (prev >> 1) | prev2) & E[DOWN ? GN - 1 : 0]);
+  if (EVAL) GO_POPC_ACC(nlib, ((prev << 1) | (prev >> 1) | prev2) & E[DOWN ? GN - 1 : 0]);
 }
 
 // grow F (subset of M) to the complete M-components it touches; every lane of the wave takes part
