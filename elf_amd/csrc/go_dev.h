@@ -131,7 +131,11 @@ __device__ inline int go_legal_rows(const GoS& s, uint32_t (&L)[GN], int (&inc)[
     E[i] = ~(s.P[i] | s.Q[i]) & FULL;
     T[i] = E[i] | (s.P[i] & ~s.AT[i]) | (s.Q[i] & s.AT[i]);
   }
-  const uint32_t kr = s.ko == NO_POINT ? 99u : s.ko / 19u, kb = s.ko == NO_POINT ? 0u : 1u << (s.ko % 19u);
+  uint32_t kr = s.ko == NO_POINT ? 99u : s.ko / 19u;
+  const uint32_t kb = s.ko == NO_POINT ? 0u : 1u << (s.ko - kr * 19u);
+  // kr is used as a row number: left to itself the compiler turns every "row == kr" into a range test on the point
+  // (add, compare, select per row) to save this one division
+  asm volatile("" : "+v"(kr));
   int n = 0;
   ROWS(i) {
     uint32_t l = E[i] & NBR(T, i);
