@@ -216,6 +216,7 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
           }
           const uint32_t cmask = gballot(counted != 0, g);
           // the reference's own loop over the edges, in edge order, on values broadcast inside the group
+#ifdef QUAD_SCAN_BRANCHY   // A/B only
           auto scan = [&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const float sk = rowbcast<k>(score);
@@ -224,6 +225,22 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
             if (valid && (sk > best || bestj == 0x7FFFFFFF)) { best = sk; bestj = base + k; }
             if (valid && ((cmask >> k) & 1)) { total_uq += uk; total_cnt++; }
           };
+#else
+          // Branch-free: a slot past the node's last edge (or a group that is not descending) holds score -inf and is
+          // not in cmask, so it can neither win nor be counted - no "valid" test, and selects instead of the two
+          // exec-masked regions per step the compiler made of the ifs.  (A group that is not descending may
+          // overwrite its best / bestj here: nothing of it is used.)
+          auto scan = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const float sk = rowbcast<k>(score);
+            const float uk = rowbcast<k>(uq);
+            const bool take = sk > best || bestj == 0x7FFFFFFF;
+            best = take ? sk : best; bestj = take ? base + k : bestj;
+            const uint32_t bit = (cmask >> k) & 1u;
+            const float su = total_uq + uk;
+            total_uq = bit ? su : total_uq; total_cnt += (int)bit;
+          };
+#endif
           for_each_k(scan, std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>{});
           if (__any(go && ne - base > 8))   // most checkers nodes have at most eight edges
             for_each_k(scan, std::integer_sequence<int, 8, 9, 10, 11, 12, 13, 14, 15>{});
