@@ -230,16 +230,17 @@ __global__ void __launch_bounds__(64) quad_search_kernel(TreeDev d, Opt o) {
           // not in cmask, so it can neither win nor be counted - no "valid" test, and selects instead of the two
           // exec-masked regions per step the compiler made of the ifs.  (A group that is not descending may
           // overwrite its best / bestj here: nothing of it is used.)
+          // An edge that is not counted adds -0.0f to the sum (x + -0.0f == x for every x, signed zeros included),
+          // so the sum needs no select; only the very first edge can be taken without being greater.
+          const float uqe = counted ? uq : -0.0f;
           auto scan = [&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const float sk = rowbcast<k>(score);
-            const float uk = rowbcast<k>(uq);
-            const bool take = sk > best || bestj == 0x7FFFFFFF;
+            total_uq += rowbcast<k>(uqe);
+            const bool take = k == 0 ? (sk > best || bestj == 0x7FFFFFFF) : sk > best;
             best = take ? sk : best; bestj = take ? base + k : bestj;
-            const uint32_t bit = (cmask >> k) & 1u;
-            const float su = total_uq + uk;
-            total_uq = bit ? su : total_uq; total_cnt += (int)bit;
           };
+          total_cnt += __popc(cmask);
 #endif
           for_each_k(scan, std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>{});
           if (__any(go && ne - base > 8))   // most checkers nodes have at most eight edges
